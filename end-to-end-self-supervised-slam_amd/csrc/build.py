@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Build libe2eslam_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python end-to-end-self-supervised-slam_amd/csrc/build.py [--force] [--asm]
+
+Objects land in csrc/_obj/, the shared library in ../lib/libe2eslam_hip.so (git-ignored; it
+travels to the GPU box with the repo snapshot).  -ffp-contract=off: the association / fusion
+kernels must evaluate fp32 expressions exactly as the CPU oracle does (no implicit FMA); where a
+fused multiply-add is wanted the source says fmaf().
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OBJ = os.path.join(HERE, "_obj")
+LIBDIR = os.path.join(os.path.dirname(HERE), "lib")
+LIB = os.path.join(LIBDIR, "libe2eslam_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++17", "-Wall",
+         "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def sources():
+    return sorted(f for f in os.listdir(HERE) if f.endswith((".hip", ".cpp")))
+
+
+def newest_header():
+    hs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
+    hs.append(os.path.join(HERE, "..", "..", "include", "e2eslam.h"))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def compile_one(src, force, asm):
+    obj = os.path.join(OBJ, src + ".o")
+    sp = os.path.join(HERE, src)
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), newest_header())):
+        return obj, ""
+    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+    if asm:
+        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+    return obj, r.stderr
+
+
+def build(force=False, asm=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = sources()
+    with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        res = list(ex.map(lambda s: compile_one(s, force, asm), srcs))
+    objs = [o for o, _ in res]
+    for _, log in res:
+        if log and verbose:
+            sys.stderr.write(log)
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, asm="--asm" in sys.argv))

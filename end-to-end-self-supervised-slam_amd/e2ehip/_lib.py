@@ -1,0 +1,97 @@
+"""ctypes binding of libe2eslam_hip.so (the C ABI declared in include/e2eslam.h).
+
+There is deliberately NO fallback: if the shared library is missing or a tensor is not on a HIP
+device the call raises.  The CPU restatement lives in oracle/ and is test infrastructure only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libe2eslam_hip.so")
+
+c_fp = ctypes.c_void_p
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_f32 = ctypes.c_float
+
+
+class Strides(ctypes.Structure):
+    _fields_ = [("sb", c_i64), ("sc", c_i64), ("sh", c_i64), ("sw", c_i64)]
+
+
+class E2EError(RuntimeError):
+    pass
+
+
+# name -> argtypes (restype int unless listed in _RESTYPE)
+SIGNATURES = {
+    "e2e_version": [],
+    "e2e_last_error": [],
+    "e2e_backproject_fwd": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "e2e_backproject_bwd": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "e2e_project3d_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "e2e_project3d_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "e2e_grid_sample_fwd": [c_fp, Strides, c_fp, c_fp] + [c_int] * 8 + [c_fp],
+    "e2e_grid_sample_bwd": [c_fp, Strides, c_fp, c_fp, c_fp, c_fp] + [c_int] * 8 + [c_fp],
+    "e2e_photometric_fwd": [c_fp, Strides, c_fp, Strides, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp],
+    "e2e_photometric_bwd": [c_fp, Strides, c_fp, Strides, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp],
+    "e2e_warp_photo_workspace_floats": [c_int, c_int, c_int],
+    "e2e_warp_photo_fwd": [c_fp, c_fp, Strides, c_fp, Strides, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int,
+                           c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "e2e_warp_photo_bwd": [c_fp, c_fp, Strides, c_fp, Strides, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int,
+                           c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+}
+_RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats": c_i64}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises E2EError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise E2EError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
+                           "(there is no CPU / PyTorch fallback for the hot path)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPE.get(name, c_int)
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise E2EError(f"{name} failed ({rc}): {lib.e2e_last_error().decode()}")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dev(t, name="tensor", dtype=torch.float32):
+    """Validate a tensor for the HIP path and return it."""
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise E2EError(f"{name}: the e2eslam hot path runs on the HIP device only (got a {t.device} tensor); "
+                       "there is no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def strides4(t):
+    """Element strides of a (B,C,H,W)-indexed view."""
+    s = t.stride()
+    return Strides(s[0], s[1], s[2], s[3])

@@ -1,0 +1,244 @@
+"""torch.autograd glue over the C ABI (include/e2eslam.h).  Device memory, streams and autograd
+bookkeeping come from PyTorch-ROCm; every computation below is a hand-written HIP kernel."""
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib as L
+
+PADDING = {"zeros": 0, "border": 1}
+
+
+def _padding(mode):
+    if mode not in PADDING:
+        raise ValueError(f"padding_mode '{mode}' is not supported by the HIP path (zeros | border)")
+    return PADDING[mode]
+
+
+def _mat(t, name, B):
+    t = L.dev(t, name)
+    if t.shape != (B, 4, 4):
+        raise ValueError(f"{name}: expected shape ({B},4,4), got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+class _Backproject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, inv_K):
+        B, _, H, W = depth.shape
+        d = L.dev(depth, "depth").contiguous()
+        ik = _mat(inv_K, "inv_K", B)
+        out = torch.empty(B, 4, H * W, device=d.device, dtype=torch.float32)
+        L.call("e2e_backproject_fwd", L.ptr(d), L.ptr(ik), L.ptr(out), B, H, W, L.stream())
+        ctx.save_for_backward(ik)
+        ctx.dims = (B, H, W)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        ik, = ctx.saved_tensors
+        B, H, W = ctx.dims
+        g = g.contiguous()
+        gd = torch.empty(B, 1, H, W, device=g.device, dtype=torch.float32)
+        L.call("e2e_backproject_bwd", L.ptr(g), L.ptr(ik), L.ptr(gd), B, H, W, L.stream())
+        return gd, None
+
+
+def backproject(depth, inv_K):
+    """BackprojectDepth.forward -- view_synthesis.py:34-40."""
+    if depth.dim() != 4 or depth.shape[1] != 1:
+        raise ValueError(f"depth: expected (B,1,H,W), got {tuple(depth.shape)}")
+    return _Backproject.apply(depth, inv_K)
+
+
+class _Project3D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, K, T, H, W, geometric):
+        B = points.shape[0]
+        p = L.dev(points, "points").contiguous()
+        K, T = _mat(K, "K", B), _mat(T, "T", B)
+        grid = torch.empty(B, H, W, 2, device=p.device, dtype=torch.float32)
+        valid = torch.empty(B, 1, H, W, device=p.device, dtype=torch.float32)
+        z = torch.empty(B, 1, H, W, device=p.device, dtype=torch.float32) if geometric else None
+        L.call("e2e_project3d_fwd", L.ptr(p), L.ptr(K), L.ptr(T), L.ptr(grid), L.ptr(valid), L.ptr(z), B, H, W, L.stream())
+        ctx.save_for_backward(p, K, T)
+        ctx.dims = (B, H, W)
+        ctx.mark_non_differentiable(valid)
+        if geometric:
+            return grid, z, valid
+        return grid, valid
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_grid, *rest):
+        p, K, T = ctx.saved_tensors
+        B, H, W = ctx.dims
+        g_z = rest[0] if len(rest) == 2 else None
+        g_grid = (g_grid if g_grid is not None else torch.zeros(B, H, W, 2, device=p.device)).contiguous()
+        g_z = g_z.contiguous() if g_z is not None else None
+        gp = torch.empty_like(p)
+        L.call("e2e_project3d_bwd", L.ptr(p), L.ptr(K), L.ptr(T), L.ptr(g_grid), L.ptr(g_z), L.ptr(gp), B, H, W, L.stream())
+        return gp, None, None, None, None, None
+
+
+def project3d(points, K, T, height, width, geometric=False):
+    """Project3D.forward -- view_synthesis.py:54-78."""
+    if points.dim() != 3 or points.shape[1] != 4 or points.shape[2] != height * width:
+        raise ValueError(f"points: expected (B,4,{height * width}), got {tuple(points.shape)}")
+    return _Project3D.apply(points, K, T, height, width, bool(geometric))
+
+
+class _GridSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, grid, pad, align):
+        B, C, Hi, Wi = inp.shape
+        _, Ho, Wo, _ = grid.shape
+        inp = L.dev(inp, "input")
+        grid = L.dev(grid, "grid").contiguous()
+        out = torch.empty(B, C, Ho, Wo, device=inp.device, dtype=torch.float32)
+        L.call("e2e_grid_sample_fwd", L.ptr(inp), L.strides4(inp), L.ptr(grid), L.ptr(out), B, C, Hi, Wi, Ho, Wo, pad, int(align), L.stream())
+        ctx.save_for_backward(inp, grid)
+        ctx.cfg = (pad, int(align))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        inp, grid = ctx.saved_tensors
+        pad, align = ctx.cfg
+        B, C, Hi, Wi = inp.shape
+        _, Ho, Wo, _ = grid.shape
+        g = g.contiguous()
+        gg = torch.empty_like(grid)
+        gi = torch.zeros(B, C, Hi, Wi, device=g.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        L.call("e2e_grid_sample_bwd", L.ptr(inp), L.strides4(inp), L.ptr(grid), L.ptr(g), L.ptr(gg), L.ptr(gi),
+               B, C, Hi, Wi, Ho, Wo, pad, align, L.stream())
+        return gi, gg, None, None
+
+
+def grid_sample(input, grid, mode="bilinear", padding_mode="zeros", align_corners=False):
+    """F.grid_sample as the reference calls it (online_adaption.py:431-439,450-453)."""
+    if mode != "bilinear":
+        raise ValueError("only bilinear sampling is on the reference's path")
+    if input.dim() != 4 or grid.dim() != 4 or grid.shape[-1] != 2 or grid.shape[0] != input.shape[0]:
+        raise ValueError(f"grid_sample: bad shapes input {tuple(input.shape)} grid {tuple(grid.shape)}")
+    return _GridSample.apply(input, grid, _padding(padding_mode), bool(align_corners))
+
+
+class _Photometric(torch.autograd.Function):
+    """returns (ssim (B,C,H,W), pmap (B,1,H,W)); either may be unused by the caller."""
+
+    @staticmethod
+    def forward(ctx, x, y, want_ssim, want_pmap):
+        B, C, H, W = x.shape
+        x, y = L.dev(x, "prediction"), L.dev(y, "target")
+        ssim = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32) if want_ssim else None
+        pmap = torch.empty(B, 1, H, W, device=x.device, dtype=torch.float32) if want_pmap else None
+        L.call("e2e_photometric_fwd", L.ptr(x), L.strides4(x), L.ptr(y), L.strides4(y), L.ptr(ssim), L.ptr(pmap), B, C, H, W, L.stream())
+        ctx.save_for_backward(x, y)
+        return ssim, pmap
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_ssim, g_pmap):
+        x, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g_ssim = g_ssim.contiguous() if g_ssim is not None else None
+        g_pmap = g_pmap.contiguous() if g_pmap is not None else None
+        gx = gy = None
+        if g_ssim is None and g_pmap is None:
+            return None, None, None, None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+            L.call("e2e_photometric_bwd", L.ptr(x), L.strides4(x), L.ptr(y), L.strides4(y), L.ptr(g_pmap), L.ptr(g_ssim), L.ptr(gx), B, C, H, W, L.stream())
+        if ctx.needs_input_grad[1]:
+            gy = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+            L.call("e2e_photometric_bwd", L.ptr(y), L.strides4(y), L.ptr(x), L.strides4(x), L.ptr(g_pmap), L.ptr(g_ssim), L.ptr(gy), B, C, H, W, L.stream())
+        return gx, gy, None, None
+
+
+def _check_pair(x, y):
+    if x.dim() != 4 or x.shape != y.shape:
+        raise ValueError(f"expected two (B,C,H,W) tensors of equal shape, got {tuple(x.shape)} / {tuple(y.shape)}")
+
+
+def ssim(x, y):
+    """SSIM.forward -- losses.py:23-37."""
+    _check_pair(x, y)
+    return _Photometric.apply(x, y, True, False)[0]
+
+
+def photometric(prediction, target):
+    """photometric_loss -- losses.py:97-117 (0.85 mean_c SSIM + 0.15 mean_c L1)."""
+    _check_pair(prediction, target)
+    return _Photometric.apply(prediction, target, False, True)[1]
+
+
+# ---------------------------------------------------------------------------------------------
+class _WarpPhotometric(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth_tgt, depth_src, init_tgt, init_src, src, tgt, K, inv_K, T, pad, use_mask, reg_kind, want_pmap):
+        B, _, H, W = depth_tgt.shape
+        dt = L.dev(depth_tgt, "depth_tgt").contiguous()
+        src, tgt = L.dev(src, "source_frame"), L.dev(tgt, "target_frame")
+        K, inv_K, T = _mat(K, "K", B), _mat(inv_K, "inv_K", B), _mat(T, "T", B)
+        ds = it = is_ = None
+        if reg_kind:
+            ds = L.dev(depth_src, "depth_src").contiguous()
+            it, is_ = L.dev(init_tgt, "init_tgt").contiguous(), L.dev(init_src, "init_src").contiguous()
+        dev = dt.device
+        synth = torch.empty(B, 3, H, W, device=dev, dtype=torch.float32)
+        valid = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32)
+        pmap = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if want_pmap else None
+        loss = torch.zeros(2, device=dev, dtype=torch.float32)
+        ws = torch.empty(L.load().e2e_warp_photo_workspace_floats(B, H, W), device=dev, dtype=torch.float32)
+        L.call("e2e_warp_photo_fwd", L.ptr(dt), L.ptr(src), L.strides4(src), L.ptr(tgt), L.strides4(tgt), L.ptr(K), L.ptr(inv_K),
+               L.ptr(T), L.ptr(synth), L.ptr(valid), L.ptr(pmap), int(use_mask), pad, reg_kind, L.ptr(it), L.ptr(is_), L.ptr(ds),
+               L.ptr(loss), L.ptr(ws), B, H, W, L.stream())
+        ctx.save_for_backward(dt, ds, it, is_, src, tgt, K, inv_K, T, synth, valid)
+        ctx.cfg = (pad, int(use_mask), reg_kind, B, H, W)
+        ctx.mark_non_differentiable(synth, valid)
+        if pmap is not None:
+            ctx.mark_non_differentiable(pmap)
+        return loss[0], loss[1], synth, valid, pmap
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g0, g1, *_):
+        dt, ds, it, is_, src, tgt, K, inv_K, T, synth, valid = ctx.saved_tensors
+        pad, use_mask, reg_kind, B, H, W = ctx.cfg
+        z = torch.zeros((), device=dt.device)
+        gl = torch.stack([g0 if g0 is not None else z, g1 if g1 is not None else z]).contiguous()
+        gdt = torch.empty(B, 1, H, W, device=dt.device, dtype=torch.float32)
+        gds = torch.empty(B, 1, H, W, device=dt.device, dtype=torch.float32) if reg_kind else None
+        L.call("e2e_warp_photo_bwd", L.ptr(dt), L.ptr(src), L.strides4(src), L.ptr(tgt), L.strides4(tgt), L.ptr(K), L.ptr(inv_K),
+               L.ptr(T), L.ptr(synth), L.ptr(valid), use_mask, pad, reg_kind, L.ptr(it), L.ptr(is_), L.ptr(ds), L.ptr(gl),
+               L.ptr(gdt), L.ptr(gds), B, H, W, L.stream())
+        return (gdt, gds) + (None,) * 11
+
+
+def warp_photometric(depth_tgt, src, tgt, K, inv_K, T, padding_mode="border", use_mask=True,
+                     depth_src=None, init_tgt=None, init_src=None, reg_kind=None, want_pmap=False):
+    """Fused image-space part of one refinement step (2 launches forward, 1 backward).
+
+    depth_tgt (B,1,H,W); src/tgt (B,3,H,W) views (NHWC memory welcome); K, inv_K, T (B,4,4).
+    reg_kind None | "l1" | "l2" adds mean-reg(init_tgt, depth_tgt) + mean-reg(init_src, depth_src).
+    Returns dict(photometric, reg, synth, valid, pmap).
+    reference: online_adaption.py:412-455, :544-564, :482-511, :612-623."""
+    if depth_tgt.dim() != 4 or depth_tgt.shape[1] != 1:
+        raise ValueError(f"depth_tgt: expected (B,1,H,W), got {tuple(depth_tgt.shape)}")
+    B, _, H, W = depth_tgt.shape
+    for n, t in (("source_frame", src), ("target_frame", tgt)):
+        if tuple(t.shape) != (B, 3, H, W):
+            raise ValueError(f"{n}: expected ({B},3,{H},{W}), got {tuple(t.shape)}")
+    rk = {None: 0, "l1": 1, "l2": 2}.get(reg_kind, -1)
+    if rk < 0:
+        raise ValueError("please specify a correct norm")          # losses.py:146
+    if rk:
+        for n, t in (("depth_src", depth_src), ("init_tgt", init_tgt), ("init_src", init_src)):
+            if t is None or tuple(t.shape) != (B, 1, H, W):
+                raise ValueError(f"{n}: expected ({B},1,{H},{W})")
+    p, r, synth, valid, pmap = _WarpPhotometric.apply(depth_tgt, depth_src, init_tgt, init_src, src, tgt, K, inv_K, T,
+                                                      _padding(padding_mode), bool(use_mask), rk, bool(want_pmap))
+    return {"photometric": p, "reg": r, "synth": synth, "valid": valid, "pmap": pmap}

@@ -1,0 +1,139 @@
+/* e2eslam.h -- C ABI of libe2eslam_hip.so: the MI355X (gfx950) implementation of the
+ * online-refinement hot path of ivanalberico/End-To-End-Self-Supervised-SLAM.
+ *
+ * The reference has no FFI layer: its boundary for this path is the Python import surface of
+ * online_adaption.py:15-36 / train_depth.py:17-38.  These entry points are what a
+ * ctypes binding of that surface calls; each one cites the reference interface it replaces.
+ * The Python host side lives in end-to-end-self-supervised-slam_amd/ (same module / class /
+ * function names as the reference); INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 (or int64 / int32 where stated) unless marked `host`;
+ *  - the caller owns every buffer (torch allocator); the library allocates nothing;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); no call synchronises;
+ *  - return value 0 = OK, negative = E2E_ERR_*; e2e_last_error() gives a thread-local message;
+ *  - image tensors are addressed through ELEMENT strides (sb, sc, sh, sw) so that the
+ *    reference's NHWC frame stack (online_adaption.py:215-220) and its permuted NCHW views
+ *    (online_adaption.py:393-394) are read in place, without a layout copy;
+ *  - results are deterministic run to run: no floating-point atomics on any parity output.
+ */
+#ifndef E2ESLAM_H
+#define E2ESLAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E2E_OK 0
+#define E2E_ERR_ARG (-1)      /* bad argument (null pointer, non-positive size, unknown enum) */
+#define E2E_ERR_LAUNCH (-2)   /* HIP reported a launch error */
+#define E2E_ERR_WORKSPACE (-3)/* caller-provided workspace too small */
+
+#define E2E_PADDING_ZEROS 0   /* MODEL.padding_mode: zeros  (configs/config.yaml:35) */
+#define E2E_PADDING_BORDER 1  /* MODEL.padding_mode: border */
+
+/* element strides of a (B,C,H,W)-indexed fp32 image */
+typedef struct e2e_strides {
+    int64_t sb, sc, sh, sw;
+} e2e_strides;
+
+int e2e_version(void);
+const char* e2e_last_error(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* View synthesis -- depth_estimation/view_synthesis.py                                         */
+/* ------------------------------------------------------------------------------------------ */
+
+/* BackprojectDepth.forward (view_synthesis.py:34-40): depth (B,H*W), inv_K (B,4,4)
+ * -> cam_points (B,4,H*W) rows x,y,z,1. */
+int e2e_backproject_fwd(const float* depth, const float* inv_K, float* cam_points,
+                        int B, int H, int W, void* stream);
+/* its autograd: g_cam (B,4,H*W) -> g_depth (B,H*W). */
+int e2e_backproject_bwd(const float* g_cam, const float* inv_K, float* g_depth,
+                        int B, int H, int W, void* stream);
+
+/* Project3D.forward (view_synthesis.py:54-78): points (B,4,H*W), K, T (B,4,4)
+ * -> grid (B,H,W,2) normalised with /(W-1),/(H-1); valid (B,H,W) = max|grid|<=1 as 0/1 float;
+ * z_out (B,H,W) = clamp(c2, 1e-3) when non-NULL (geometric=True, view_synthesis.py:73-76). */
+int e2e_project3d_fwd(const float* points, const float* K, const float* T, float* grid, float* valid,
+                      float* z_out, int B, int H, int W, void* stream);
+/* autograd of the above: g_grid (B,H,W,2), g_z (B,H,W) or NULL -> g_points (B,4,H*W). */
+int e2e_project3d_bwd(const float* points, const float* K, const float* T, const float* g_grid,
+                      const float* g_z, float* g_points, int B, int H, int W, void* stream);
+
+/* F.grid_sample(input, grid, mode="bilinear", padding_mode, align_corners) as called at
+ * online_adaption.py:431-439,450-453.  input (B,C,Hi,Wi) via strides, grid (B,Ho,Wo,2) contiguous,
+ * out (B,C,Ho,Wo) contiguous. */
+int e2e_grid_sample_fwd(const float* input, e2e_strides in_strides, const float* grid, float* out,
+                        int B, int C, int Hi, int Wi, int Ho, int Wo, int padding_mode,
+                        int align_corners, void* stream);
+/* g_out (B,C,Ho,Wo) contiguous -> g_grid (B,Ho,Wo,2); if g_input != NULL it must be a ZEROED
+ * contiguous (B,C,Hi,Wi) buffer that receives the scatter-add (only the geometric branch,
+ * online_adaption.py:436-439, needs it; this one output uses float atomics). */
+int e2e_grid_sample_bwd(const float* input, e2e_strides in_strides, const float* grid,
+                        const float* g_out, float* g_grid, float* g_input, int B, int C, int Hi,
+                        int Wi, int Ho, int Wo, int padding_mode, int align_corners, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Photometric loss -- loss/losses.py                                                           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* SSIM.forward (losses.py:23-37) and photometric_loss (losses.py:97-117) in one pass.
+ * x = prediction, y = target, both (B,C,H,W) via strides.
+ * ssim_out (B,C,H,W) contiguous or NULL; pmap_out (B,1,H,W) contiguous or NULL
+ * (pmap = 0.85*mean_c ssim + 0.15*mean_c |y-x|). */
+int e2e_photometric_fwd(const float* x, e2e_strides xs, const float* y, e2e_strides ys,
+                        float* ssim_out, float* pmap_out, int B, int C, int H, int W, void* stream);
+/* Gradient wrt x.  g_pmap (B,1,H,W) or NULL, g_ssim (B,C,H,W) or NULL (both contiguous; the two
+ * contributions add) -> g_x (B,C,H,W) contiguous.  Gradient wrt y: call with x and y swapped
+ * (SSIM is symmetric; the L1 term's sign flips with the swap, as it must). */
+int e2e_photometric_bwd(const float* x, e2e_strides xs, const float* y, e2e_strides ys,
+                        const float* g_pmap, const float* g_ssim, float* g_x, int B, int C, int H,
+                        int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Fused refinement-step kernels (what the build's own driver launches)                         */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Number of floats of workspace the fused forward needs for (B,H,W). */
+int64_t e2e_warp_photo_workspace_floats(int B, int H, int W);
+
+/* Forward of one refinement step's image-space part, ONE launch (+ a 1-block reduction):
+ *   backproject -> project -> grid_sample(src) -> mask -> masked SSIM+L1 -> mean   [+ depth reg.]
+ * reference: online_adaption.py:412-455 (novel_view_synthesis), :544-564, :482-511, :612-623.
+ *   depth_tgt (B,H,W)   target depth (after median scaling)
+ *   src, tgt            source / target frame, (B,3,H,W) via strides (NHWC memory is fine)
+ *   K, inv_K, T         (B,4,4)
+ *   synth (B,3,H,W), valid (B,H,W)   outputs kept for the backward
+ *   pmap (B,H,W) or NULL             per-pixel loss map
+ *   use_mask            LOSS.photometric_mask
+ *   reg_kind            0 = no depth regulariser, 1 = l1, 2 = l2 (losses.py:134-148); when != 0:
+ *     reg_init_tgt, reg_init_src (B,H,W)  initial depths (online_adaption.py:284-285)
+ *     depth_src (B,H,W)                    refined depth of the source frame
+ *   loss_out[0] = photometric mean, loss_out[1] = mean-reg(tgt) + mean-reg(src)
+ *   workspace: e2e_warp_photo_workspace_floats floats. */
+int e2e_warp_photo_fwd(const float* depth_tgt, const float* src, e2e_strides src_strides,
+                       const float* tgt, e2e_strides tgt_strides, const float* K, const float* inv_K,
+                       const float* T, float* synth, float* valid, float* pmap, int use_mask,
+                       int padding_mode, int reg_kind, const float* reg_init_tgt,
+                       const float* reg_init_src, const float* depth_src, float* loss_out,
+                       float* workspace, int B, int H, int W, void* stream);
+
+/* Backward of the above, ONE launch.
+ *   g_loss (device, 2 floats): upstream gradients of loss_out[0] and loss_out[1]
+ *   g_depth_tgt (B,H,W) = d/d(depth_tgt) of g_loss[0]*photometric + g_loss[1]*reg
+ *   g_depth_src (B,H,W) = d/d(depth_src) of g_loss[1]*reg   (written only when reg_kind != 0;
+ *   the warp reads the TARGET depth only: online_adaption.py:419). */
+int e2e_warp_photo_bwd(const float* depth_tgt, const float* src, e2e_strides src_strides,
+                       const float* tgt, e2e_strides tgt_strides, const float* K, const float* inv_K,
+                       const float* T, const float* synth, const float* valid, int use_mask,
+                       int padding_mode, int reg_kind, const float* reg_init_tgt,
+                       const float* reg_init_src, const float* depth_src, const float* g_loss,
+                       float* g_depth_tgt, float* g_depth_src, int B, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E2ESLAM_H */

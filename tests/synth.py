@@ -1,0 +1,42 @@
+"""Seeded synthetic inputs shared by the tests, smoke() and bench.py."""
+import math
+
+import torch
+
+
+def icl_K(H, W):
+    K = torch.eye(4)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = 481.2 * W / 640, -480.0 * H / 480, 319.5 * W / 640, 239.5 * H / 480
+    return K.unsqueeze(0)
+
+
+def motion(rz_deg=1.0, ry_deg=0.5, t=(0.05, 0.01, 0.02)):
+    a, b = math.radians(rz_deg), math.radians(ry_deg)
+    Rz = torch.tensor([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1.0]])
+    Ry = torch.tensor([[math.cos(b), 0, math.sin(b)], [0, 1.0, 0], [-math.sin(b), 0, math.cos(b)]])
+    T = torch.eye(4)
+    T[:3, :3] = Rz @ Ry
+    T[:3, 3] = torch.tensor(t)
+    return T.unsqueeze(0)
+
+
+def smooth_depth(H, W, g):
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    d = 2.0 + 0.5 * torch.sin(2 * math.pi * xs / W) * torch.cos(2 * math.pi * ys / H) + 0.05 * torch.rand(H, W, generator=g)
+    return d.view(1, 1, H, W)
+
+
+def smooth_image(H, W, g):
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    ch = [0.5 + 0.3 * torch.sin(xs * (0.11 + 0.05 * c) + c) * torch.cos(ys * (0.07 + 0.03 * c)) for c in range(3)]
+    return (torch.stack(ch, -1) + 0.2 * torch.rand(H, W, 3, generator=g)).clamp(0, 1).unsqueeze(0)
+
+
+def make_pair(H, W, seed=1234, B=1, rz=1.0, ry=0.5, t=(0.05, 0.01, 0.02)):
+    """depth (B,1,H,W), src/tgt (B,H,W,3) NHWC, K/invK/T (B,4,4) -- CPU tensors."""
+    g = torch.Generator().manual_seed(seed)
+    depth = torch.cat([smooth_depth(H, W, g) for _ in range(B)], 0)
+    src = torch.cat([smooth_image(H, W, g) for _ in range(B)], 0)
+    tgt = torch.cat([smooth_image(H, W, g) for _ in range(B)], 0)
+    K = icl_K(H, W).repeat(B, 1, 1)
+    return dict(depth=depth, src=src, tgt=tgt, K=K, invK=torch.pinverse(K), T=motion(rz, ry, t).repeat(B, 1, 1))

@@ -1,0 +1,188 @@
+"""HIP warp / photometric kernels (through the C ABI) against the CPU oracle and the golden vectors."""
+import pytest
+import torch
+
+from oracle import warp_loss
+from synth import make_pair
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+# fp32 tolerance named by BASELINE.json north_star: 1e-4 relative on depth / loss tensors
+RTOL = 1e-4
+
+
+def _ops():
+    from e2ehip import ops
+    return ops
+
+
+def _close(a, b, rtol=RTOL, atol=1e-6, what=""):
+    torch.testing.assert_close(a.detach().cpu(), b.detach().cpu(), rtol=rtol, atol=atol, msg=lambda m: f"{what}: {m}")
+
+
+def _grad_close(a, b, rel=1e-3, what=""):
+    """gradients: compare against the tensor's own scale (tiny entries carry cancellation noise)."""
+    a, b = a.detach().cpu(), b.detach().cpu()
+    scale = b.abs().max().item() + 1e-30
+    err = (a - b).abs().max().item() / scale
+    assert err < rel, f"{what}: max err / max|ref| = {err:.3e}"
+
+
+def _mask_close(a, b, grid, what=""):
+    """0/1 validity masks must agree except where |grid| sits within rounding of the boundary 1.0."""
+    a, b = a.detach().cpu(), b.detach().cpu()
+    diff = (a != b)
+    if diff.any():
+        edge = (grid.abs().max(-1)[0] - 1).abs().unsqueeze(1)
+        assert (edge[diff] < 1e-5).all(), f"{what}: mask differs away from the boundary"
+        assert diff.sum() <= 4
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_modular_ops_vs_golden(golden, tag):
+    ops = _ops()
+    g = golden(f"g1_warp_{tag}")
+    H, W = g["depth"].shape[2:]
+    d = g["depth"].to(DEV).requires_grad_(True)
+    cam = ops.backproject(d, g["invK"].to(DEV))
+    _close(cam, g["cam"], what="cam")
+    grid, valid = ops.project3d(cam, g["K"].to(DEV), g["T"].to(DEV), H, W)
+    _close(grid, g["grid"], atol=2e-6, what="grid")
+    _mask_close(valid, g["valid"], g["grid"], "valid")
+    src = g["src"].to(DEV).permute(0, 3, 1, 2)
+    tgt = g["tgt"].to(DEV).permute(0, 3, 1, 2)
+    for pad in ("border", "zeros"):
+        synth = ops.grid_sample(src, grid, padding_mode=pad, align_corners=False)
+        _close(synth, g[f"{pad}_synth"], atol=1e-5, what=f"synth {pad}")
+        pm = ops.photometric(synth * valid, tgt * valid)
+        _close(pm, g[f"{pad}_pmap"], atol=1e-5, what=f"pmap {pad}")
+        loss = pm.mean(1, keepdim=True).mean()
+        _close(loss, g[f"{pad}_loss"], what=f"loss {pad}")
+        gd, = torch.autograd.grad(loss, d, retain_graph=True)
+        _grad_close(gd, g[f"{pad}_gdepth"], what=f"gdepth {pad}")
+    gridg, zg, _ = ops.project3d(cam, g["K"].to(DEV), g["T"].to(DEV), H, W, geometric=True)
+    _close(zg, g["geo_depth"], what="geo depth")
+    _close(ops.grid_sample(src, gridg, padding_mode="border", align_corners=True), g["geo_synth_ac"], atol=1e-5, what="align_corners")
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("pad", ["border", "zeros"])
+def test_fused_vs_golden(golden, tag, pad):
+    ops = _ops()
+    g = golden(f"g1_warp_{tag}")
+    d = g["depth"].to(DEV).requires_grad_(True)
+    src, tgt = g["src"].to(DEV).permute(0, 3, 1, 2), g["tgt"].to(DEV).permute(0, 3, 1, 2)
+    out = ops.warp_photometric(d, src, tgt, g["K"].to(DEV), g["invK"].to(DEV), g["T"].to(DEV), padding_mode=pad, want_pmap=True)
+    _close(out["synth"], g[f"{pad}_synth"], atol=1e-5, what="synth")
+    _mask_close(out["valid"], g["valid"], g["grid"], "valid")
+    _close(out["pmap"], g[f"{pad}_pmap"], atol=1e-5, what="pmap")
+    _close(out["photometric"], g[f"{pad}_loss"], what="loss")
+    out["photometric"].backward()
+    _grad_close(d.grad, g[f"{pad}_gdepth"], what="gdepth")
+
+
+def test_fused_nomask_vs_golden(golden):
+    ops = _ops()
+    g = golden("g1_warp_b")
+    d = g["depth"].to(DEV).requires_grad_(True)
+    src, tgt = g["src"].to(DEV).permute(0, 3, 1, 2), g["tgt"].to(DEV).permute(0, 3, 1, 2)
+    out = ops.warp_photometric(d, src, tgt, g["K"].to(DEV), g["invK"].to(DEV), g["T"].to(DEV), use_mask=False)
+    _close(out["photometric"], g["nomask_loss"], what="loss")
+    out["photometric"].backward()
+    _grad_close(d.grad, g["nomask_gdepth"], what="gdepth")
+
+
+def test_ssim_photometric_vs_golden(golden):
+    ops = _ops()
+    g = golden("g3_ssim")
+    x = g["x"].to(DEV).requires_grad_(True)
+    y = g["y"].to(DEV)
+    _close(ops.ssim(x, y), g["ssim"], atol=1e-5, what="ssim")
+    p = ops.photometric(x, y)
+    _close(p, g["pmap"], atol=1e-5, what="pmap")
+    gx, = torch.autograd.grad(p.mean(), x)
+    _grad_close(gx, g["gx"], what="gx")
+    # gradient wrt the second argument and through the per-channel SSIM map, vs the oracle's autograd
+    xc, yc = g["x"].clone().requires_grad_(True), g["y"].clone().requires_grad_(True)
+    w = torch.rand(g["ssim"].shape, generator=torch.Generator().manual_seed(0))
+    (warp_loss.ssim(xc, yc) * w).sum().backward()
+    xg, yg = g["x"].to(DEV).requires_grad_(True), g["y"].to(DEV).requires_grad_(True)
+    (ops.ssim(xg, yg) * w.to(DEV)).sum().backward()
+    _grad_close(xg.grad, xc.grad, what="ssim gx")
+    _grad_close(yg.grad, yc.grad, what="ssim gy")
+
+
+@pytest.mark.parametrize("H,W,B,pad,reg", [(37, 53, 1, "border", "l2"), (64, 96, 2, "zeros", "l1"), (8, 33, 1, "border", None),
+                                           (3, 3, 1, "border", "l2")])
+def test_fused_vs_oracle_ragged(H, W, B, pad, reg):
+    """Sizes that are not multiples of the 32x8 tile, batch > 1, both paddings, with the regulariser."""
+    ops = _ops()
+    s = make_pair(H, W, seed=H * 1000 + W, B=B, rz=3.0, ry=2.0, t=(0.2, 0.05, 0.1))
+    gen = torch.Generator().manual_seed(5)
+    dsrc = s["depth"] + 0.1 * torch.rand(s["depth"].shape, generator=gen)
+    it = s["depth"] + 0.05 * torch.rand(s["depth"].shape, generator=gen)
+    is_ = dsrc + 0.05 * torch.rand(s["depth"].shape, generator=gen)
+    # oracle
+    dc, dsc = s["depth"].clone().requires_grad_(True), dsrc.clone().requires_grad_(True)
+    synth, valid, grid = warp_loss.inverse_warp(dc, s["src"].permute(0, 3, 1, 2), s["K"], s["invK"], s["T"], pad)
+    lp, pmap = warp_loss.masked_photometric_mean(synth, s["tgt"].permute(0, 3, 1, 2), valid)
+    tot = lp * 1.7
+    if reg:
+        lr = warp_loss.depth_regularizer(it, dc, reg) + warp_loss.depth_regularizer(is_, dsc, reg)
+        tot = tot + 0.3 * lr
+    tot.backward()
+    # HIP
+    d, ds = s["depth"].to(DEV).requires_grad_(True), dsrc.to(DEV).requires_grad_(True)
+    out = ops.warp_photometric(d, s["src"].to(DEV).permute(0, 3, 1, 2), s["tgt"].to(DEV).permute(0, 3, 1, 2),
+                               s["K"].to(DEV), s["invK"].to(DEV), s["T"].to(DEV), padding_mode=pad,
+                               depth_src=ds, init_tgt=it.to(DEV), init_src=is_.to(DEV), reg_kind=reg, want_pmap=True)
+    t2 = out["photometric"] * 1.7
+    if reg:
+        _close(out["reg"], lr, what="reg")
+        t2 = t2 + 0.3 * out["reg"]
+    t2.backward()
+    _close(out["synth"], synth, atol=1e-5, what="synth")
+    _mask_close(out["valid"], valid, grid, "valid")
+    _close(out["pmap"], pmap, atol=1e-5, what="pmap")
+    _close(out["photometric"], lp, what="photometric")
+    _grad_close(d.grad, dc.grad, what="g depth_tgt")
+    if reg:
+        _grad_close(ds.grad, dsc.grad, what="g depth_src")
+
+
+def test_full_size_checksums(golden):
+    """480x640 (BASELINE size): the reference's checksums + sampled pixels, and run-to-run bit equality."""
+    ops = _ops()
+    g = golden("g9_full_checksums")
+    s = make_pair(480, 640, seed=int(g["seed"]))
+    d = s["depth"].to(DEV).requires_grad_(True)
+    args = (s["src"].to(DEV).permute(0, 3, 1, 2), s["tgt"].to(DEV).permute(0, 3, 1, 2), s["K"].to(DEV), s["invK"].to(DEV), s["T"].to(DEV))
+    out = ops.warp_photometric(d, *args, want_pmap=True)
+    out["photometric"].backward()
+    _close(out["photometric"], g["loss"], what="loss")
+    assert abs(out["valid"].sum().item() - g["valid_sum"].item()) <= 4
+    assert abs(out["synth"].double().sum().item() - g["synth_sum"].item()) < 1e-5 * g["synth_abs"].item()
+    assert abs(d.grad.double().sum().item() - g["gdepth_sum"].item()) < 1e-3 * g["gdepth_abs"].item()
+    assert abs(d.grad.double().abs().sum().item() - g["gdepth_abs"].item()) < 1e-3 * g["gdepth_abs"].item()
+    pick = g["pick"].to(DEV)
+    _close(out["synth"][0].reshape(3, -1)[:, pick], g["synth_pick"], atol=1e-5, what="synth pick")
+    _close(out["pmap"].view(-1)[pick], g["pmap_pick"], atol=1e-5, what="pmap pick")
+    _grad_close(d.grad.view(-1)[pick], g["gdepth_pick"], what="gdepth pick")
+    d2 = s["depth"].to(DEV).requires_grad_(True)
+    out2 = ops.warp_photometric(d2, *args)
+    out2["photometric"].backward()
+    assert torch.equal(out2["photometric"], out["photometric"]) and torch.equal(d2.grad, d.grad)
+
+
+def test_errors():
+    ops = _ops()
+    from e2ehip import E2EError
+    s = make_pair(16, 16)
+    with pytest.raises(E2EError):          # CPU tensors are refused: no fallback
+        ops.backproject(s["depth"], s["invK"])
+    d = s["depth"].to(DEV)
+    with pytest.raises(ValueError):
+        ops.grid_sample(s["src"].to(DEV).permute(0, 3, 1, 2), torch.zeros(1, 16, 16, 2, device=DEV), padding_mode="reflection")
+    with pytest.raises(ValueError):
+        ops.warp_photometric(d, s["src"].to(DEV).permute(0, 3, 1, 2), s["tgt"].to(DEV).permute(0, 3, 1, 2), s["K"].to(DEV),
+                             s["invK"].to(DEV), s["T"].to(DEV), reg_kind="huber")
