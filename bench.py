@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- refinement-step throughput of the MI355X hot path (see DESIGN.md "Measurement").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+
+Workload (BASELINE.json configs[1]): synthetic 640x480 RGB-D pair, image-space part of one
+refinement step = fused warp + masked SSIM/L1 photometric (+ l2 depth regulariser) forward AND
+backward, inputs resident in HBM.  One "step" = e2e_warp_photo_fwd (+1-block reduce) +
+e2e_warp_photo_bwd, replayed from a captured HIP graph.  N>1: one process per GPU, each rank owns
+its own pair (the path shards by sequence; this workload has no exchange step), value = total
+steps / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "end-to-end-self-supervised-slam_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(H, W, budget_s=12.0):
+    """The oracle (CPU restatement, kind 'port') on this node's host cores, same workload."""
+    from oracle import warp_loss
+    from synth import make_pair
+    ncpu = os.cpu_count() or 1
+    s = make_pair(H, W, seed=1234)
+    g = torch.Generator().manual_seed(5)
+    dsrc = s["depth"] + 0.1 * torch.rand(s["depth"].shape, generator=g)
+    it, is_ = s["depth"] + 0.05, dsrc + 0.05
+    src, tgt = s["src"].permute(0, 3, 1, 2), s["tgt"].permute(0, 3, 1, 2)
+
+    def step():
+        d = s["depth"].clone().requires_grad_(True)
+        ds = dsrc.clone().requires_grad_(True)
+        synth, valid, _ = warp_loss.inverse_warp(d, src, s["K"], s["invK"], s["T"], "border")
+        lp, _ = warp_loss.masked_photometric_mean(synth, tgt, valid)
+        loss = lp + 1e-2 * (warp_loss.depth_regularizer(it, d, "l2") + warp_loss.depth_regularizer(is_, ds, "l2"))
+        loss.backward()
+        return loss
+
+    # torch's intra-op pool oversubscribes badly on a many-core host for these small ops: probe a few
+    # thread counts briefly and time the best one (cores = threads actually used).
+    best = None
+    for th in sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)}):
+        torch.set_num_threads(th)
+        step()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        rate = 3 / (time.perf_counter() - t0)
+        if best is None or rate > best[0]:
+            best = (rate, th)
+    cores = best[1]
+    torch.set_num_threads(cores)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 400:
+            break
+    return {"value": n / el, "unit": "steps/s", "cores": cores, "kind": "port", "host_cpus": ncpu,
+            "sample": f"{n} fwd+bwd steps of the same 1x{H}x{W} warp+photometric+reg workload ({el:.1f} s), torch CPU, {cores} threads (best of a short sweep)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=1, help="keyframe pairs per launch (reference: 1)")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--split", action="store_true", help="two-kernel form (e2e_warp_photo_fwd + _bwd) instead of the single-launch lossgrad")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from e2ehip import _lib as L
+    from e2ehip.fused import LossGradPlan, WarpPhotoPlan
+    from synth import make_pair
+    L.load()
+    B, H, W = a.batch, a.height, a.width
+    s = make_pair(H, W, seed=1234 + rank, B=B)
+    g = torch.Generator().manual_seed(5)
+    dsrc = s["depth"] + 0.1 * torch.rand(s["depth"].shape, generator=g)
+    t = {k: v.to(dev).contiguous() for k, v in s.items()}
+    src, tgt = t["src"].permute(0, 3, 1, 2), t["tgt"].permute(0, 3, 1, 2)     # NHWC memory, NCHW view
+    plan = (WarpPhotoPlan(B, H, W, dev, "border", True, "l2") if a.split else LossGradPlan(B, H, W, dev, "border", True, "l2", 1.0, 1e-2)).bind(
+        t["depth"], dsrc.to(dev), (s["depth"] + 0.05).to(dev), (dsrc + 0.05).to(dev), src, tgt, t["K"], t["invK"], t["T"])
+
+    def step():
+        if a.split:
+            plan.forward()
+            plan.backward()
+        else:
+            plan.step()
+
+    side = torch.cuda.Stream(dev)
+    graph = None
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+        side.synchronize()
+        if not a.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                step()
+        run = graph.replay if graph is not None else step
+        for _ in range(a.warmup):
+            run()
+
+        def barrier():
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            run()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        barrier()
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+
+        # per-kernel launch durations with HIP events on the launch stream (eager, same buffers)
+        def kernel_ms(fn, reps=200):
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for e0, e1 in ev:
+                e0.record(side)
+                fn()
+                e1.record(side)
+            side.synchronize()
+            ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+            return sum(ts[reps // 10: -reps // 10]) / len(ts[reps // 10: -reps // 10])
+        N = B * H * W
+        if a.split:
+            fwd_ms = kernel_ms(plan.forward)
+            bwd_ms = kernel_ms(plan.backward)
+            # algorithmic bytes per launch: fwd reads depth 4N + src 12N + tgt 12N (+ reg 12N), writes synth 12N
+            # + valid 4N; bwd reads depth 4N + src 12N + tgt 12N + synth 12N + valid 4N (+ reg 12N), writes g_tgt 4N (+ g_src 4N)
+            fwd_bytes, bwd_bytes = (44 + 12) * N, (48 + 16) * N
+            dom, dom_ms, dom_bytes = ("e2e_warp_photo_bwd", bwd_ms, bwd_bytes) if bwd_ms >= fwd_ms else ("e2e_warp_photo_fwd(+reduce)", fwd_ms, fwd_bytes)
+            launch_ms = {"warp_photo_fwd+reduce": fwd_ms, "warp_photo_bwd": bwd_ms}
+            alg = {"fwd": fwd_bytes, "bwd": bwd_bytes}
+        else:
+            dom_ms = kernel_ms(plan.step)
+            # single launch: reads depth 4N + src 12N + tgt 12N + reg (init_t, init_s, depth_s) 12N; writes g_tgt 4N + g_src 4N
+            dom, dom_bytes = "e2e_warp_photo_lossgrad(+reduce)", 48 * N
+            launch_ms = {"warp_photo_lossgrad+reduce": dom_ms}
+            alg = {"lossgrad": dom_bytes, "survey_8d_fused_minimum_equiv": (92 + 24) * N}
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    if rank == 0:
+        out = {
+            "metric": "online refinement steps/sec @640x480", "value": world * a.steps * B / el, "unit": "steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic 640x480 RGB-D pair, warp+photometric(+l2 depth-reg) fwd+bwd kernels only",
+                       "pairs_per_launch": B, "height": H, "width": W, "launch": "eager" if graph is None else "hipGraph replay",
+                       "kernels_per_step": 3 if a.split else 2},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launch_ms": launch_ms, "algorithmic_bytes": alg},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(H, W)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

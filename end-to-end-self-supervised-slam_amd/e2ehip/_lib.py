@@ -42,8 +42,12 @@ SIGNATURES = {
                            c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
     "e2e_warp_photo_bwd": [c_fp, c_fp, Strides, c_fp, Strides, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int,
                            c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "e2e_warp_photo_lossgrad_workspace_floats": [c_int, c_int, c_int],
+    "e2e_warp_photo_lossgrad": [c_fp, c_fp, Strides, c_fp, Strides, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp,
+                                c_f32, c_f32, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
 }
-_RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats": c_i64}
+_RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats": c_i64,
+            "e2e_warp_photo_lossgrad_workspace_floats": c_i64}
 
 _lib = None
 

@@ -133,6 +133,23 @@ int e2e_warp_photo_bwd(const float* depth_tgt, const float* src, e2e_strides src
                        const float* reg_init_src, const float* depth_src, const float* g_loss,
                        float* g_depth_tgt, float* g_depth_src, int B, int H, int W, void* stream);
 
+/* The step the build's driver actually launches: loss AND gradient in ONE pass (the gradient of a
+ * mean does not depend on its value, so forward and backward of the image-space part collapse;
+ * synth / valid / the loss map never reach HBM).  Same semantics as e2e_warp_photo_fwd followed by
+ * e2e_warp_photo_bwd with upstream gradients (w_photo, w_reg):
+ *   loss_out[0] = photometric mean, loss_out[1] = regulariser (unweighted);
+ *   g_depth_tgt = d(w_photo*loss0 + w_reg*loss1)/d(depth_tgt), g_depth_src likewise (reg_kind != 0).
+ * workspace: e2e_warp_photo_lossgrad_workspace_floats floats (per-workgroup partial sums; a
+ * 2-wave second-stage kernel adds them in a fixed order => bitwise reproducible loss). */
+int64_t e2e_warp_photo_lossgrad_workspace_floats(int B, int H, int W);
+int e2e_warp_photo_lossgrad(const float* depth_tgt, const float* src, e2e_strides src_strides,
+                            const float* tgt, e2e_strides tgt_strides, const float* K,
+                            const float* inv_K, const float* T, int use_mask, int padding_mode,
+                            int reg_kind, const float* reg_init_tgt, const float* reg_init_src,
+                            const float* depth_src, float w_photo, float w_reg, float* loss_out,
+                            float* g_depth_tgt, float* g_depth_src, float* workspace, int B, int H,
+                            int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,7 @@ import pytest
 import torch
 
 from oracle import warp_loss
-from synth import make_pair
+from synth import grad_mismatch, make_pair
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -20,12 +20,25 @@ def _close(a, b, rtol=RTOL, atol=1e-6, what=""):
     torch.testing.assert_close(a.detach().cpu(), b.detach().cpu(), rtol=rtol, atol=atol, msg=lambda m: f"{what}: {m}")
 
 
+def _img_close(a, b, what=""):
+    """image-valued tensors in [0,1]: 1e-4 of the tensor's scale (bilinear taps at ix ~ 1e2..1e3 carry
+    fp32 coordinate rounding of ~1e-5 px times the local image slope)."""
+    a, b = a.detach().cpu(), b.detach().cpu()
+    err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+    assert err < RTOL, f"{what}: max err / max|ref| = {err:.3e}"
+
+
 def _grad_close(a, b, rel=1e-3, what=""):
     """gradients: compare against the tensor's own scale (tiny entries carry cancellation noise)."""
     a, b = a.detach().cpu(), b.detach().cpu()
     scale = b.abs().max().item() + 1e-30
     err = (a - b).abs().max().item() / scale
     assert err < rel, f"{what}: max err / max|ref| = {err:.3e}"
+
+
+def _gdepth_close(a, b, grid, what=""):
+    err, skipped = grad_mismatch(a, b, grid)
+    assert err < 1e-3 and skipped < 0.01, f"{what}: max err / max|ref| = {err:.3e} ({skipped:.2%} boundary pixels skipped)"
 
 
 def _mask_close(a, b, grid, what=""):
@@ -53,13 +66,13 @@ def test_modular_ops_vs_golden(golden, tag):
     tgt = g["tgt"].to(DEV).permute(0, 3, 1, 2)
     for pad in ("border", "zeros"):
         synth = ops.grid_sample(src, grid, padding_mode=pad, align_corners=False)
-        _close(synth, g[f"{pad}_synth"], atol=1e-5, what=f"synth {pad}")
+        _img_close(synth, g[f"{pad}_synth"], what=f"synth {pad}")
         pm = ops.photometric(synth * valid, tgt * valid)
-        _close(pm, g[f"{pad}_pmap"], atol=1e-5, what=f"pmap {pad}")
+        _img_close(pm, g[f"{pad}_pmap"], what=f"pmap {pad}")
         loss = pm.mean(1, keepdim=True).mean()
         _close(loss, g[f"{pad}_loss"], what=f"loss {pad}")
         gd, = torch.autograd.grad(loss, d, retain_graph=True)
-        _grad_close(gd, g[f"{pad}_gdepth"], what=f"gdepth {pad}")
+        _gdepth_close(gd, g[f"{pad}_gdepth"], g["grid"], what=f"gdepth {pad}")
     gridg, zg, _ = ops.project3d(cam, g["K"].to(DEV), g["T"].to(DEV), H, W, geometric=True)
     _close(zg, g["geo_depth"], what="geo depth")
     _close(ops.grid_sample(src, gridg, padding_mode="border", align_corners=True), g["geo_synth_ac"], atol=1e-5, what="align_corners")
@@ -73,12 +86,12 @@ def test_fused_vs_golden(golden, tag, pad):
     d = g["depth"].to(DEV).requires_grad_(True)
     src, tgt = g["src"].to(DEV).permute(0, 3, 1, 2), g["tgt"].to(DEV).permute(0, 3, 1, 2)
     out = ops.warp_photometric(d, src, tgt, g["K"].to(DEV), g["invK"].to(DEV), g["T"].to(DEV), padding_mode=pad, want_pmap=True)
-    _close(out["synth"], g[f"{pad}_synth"], atol=1e-5, what="synth")
+    _img_close(out["synth"], g[f"{pad}_synth"], what="synth")
     _mask_close(out["valid"], g["valid"], g["grid"], "valid")
-    _close(out["pmap"], g[f"{pad}_pmap"], atol=1e-5, what="pmap")
+    _img_close(out["pmap"], g[f"{pad}_pmap"], what="pmap")
     _close(out["photometric"], g[f"{pad}_loss"], what="loss")
     out["photometric"].backward()
-    _grad_close(d.grad, g[f"{pad}_gdepth"], what="gdepth")
+    _gdepth_close(d.grad, g[f"{pad}_gdepth"], g["grid"], what="gdepth")
 
 
 def test_fused_nomask_vs_golden(golden):
@@ -89,7 +102,7 @@ def test_fused_nomask_vs_golden(golden):
     out = ops.warp_photometric(d, src, tgt, g["K"].to(DEV), g["invK"].to(DEV), g["T"].to(DEV), use_mask=False)
     _close(out["photometric"], g["nomask_loss"], what="loss")
     out["photometric"].backward()
-    _grad_close(d.grad, g["nomask_gdepth"], what="gdepth")
+    _gdepth_close(d.grad, g["nomask_gdepth"], g["grid"], what="gdepth")
 
 
 def test_ssim_photometric_vs_golden(golden):
@@ -141,11 +154,11 @@ def test_fused_vs_oracle_ragged(H, W, B, pad, reg):
         _close(out["reg"], lr, what="reg")
         t2 = t2 + 0.3 * out["reg"]
     t2.backward()
-    _close(out["synth"], synth, atol=1e-5, what="synth")
+    _img_close(out["synth"], synth, what="synth")
     _mask_close(out["valid"], valid, grid, "valid")
-    _close(out["pmap"], pmap, atol=1e-5, what="pmap")
+    _img_close(out["pmap"], pmap, what="pmap")
     _close(out["photometric"], lp, what="photometric")
-    _grad_close(d.grad, dc.grad, what="g depth_tgt")
+    _gdepth_close(d.grad, dc.grad, grid, what="g depth_tgt")
     if reg:
         _grad_close(ds.grad, dsc.grad, what="g depth_src")
 
@@ -165,8 +178,8 @@ def test_full_size_checksums(golden):
     assert abs(d.grad.double().sum().item() - g["gdepth_sum"].item()) < 1e-3 * g["gdepth_abs"].item()
     assert abs(d.grad.double().abs().sum().item() - g["gdepth_abs"].item()) < 1e-3 * g["gdepth_abs"].item()
     pick = g["pick"].to(DEV)
-    _close(out["synth"][0].reshape(3, -1)[:, pick], g["synth_pick"], atol=1e-5, what="synth pick")
-    _close(out["pmap"].view(-1)[pick], g["pmap_pick"], atol=1e-5, what="pmap pick")
+    _img_close(out["synth"][0].reshape(3, -1)[:, pick], g["synth_pick"], what="synth pick")
+    _img_close(out["pmap"].view(-1)[pick], g["pmap_pick"], what="pmap pick")
     _grad_close(d.grad.view(-1)[pick], g["gdepth_pick"], what="gdepth pick")
     d2 = s["depth"].to(DEV).requires_grad_(True)
     out2 = ops.warp_photometric(d2, *args)
@@ -186,3 +199,40 @@ def test_errors():
     with pytest.raises(ValueError):
         ops.warp_photometric(d, s["src"].to(DEV).permute(0, 3, 1, 2), s["tgt"].to(DEV).permute(0, 3, 1, 2), s["K"].to(DEV),
                              s["invK"].to(DEV), s["T"].to(DEV), reg_kind="huber")
+
+
+@pytest.mark.parametrize("H,W,B,pad,reg,nhwc", [(48, 64, 1, "border", "l2", True), (37, 53, 2, "border", "l1", True),
+                                                (64, 96, 2, "zeros", "l2", True), (20, 70, 1, "border", None, False),
+                                                (3, 3, 1, "border", "l2", True), (480, 640, 1, "border", "l2", True)])
+def test_lossgrad_single_launch_vs_oracle(H, W, B, pad, reg, nhwc):
+    """e2e_warp_photo_lossgrad (loss + gradient in one pass) against the oracle's autograd."""
+    from e2ehip.fused import LossGradPlan
+    big = H >= 480
+    s = make_pair(H, W, seed=H * 1000 + W, B=B) if big else make_pair(H, W, seed=H * 1000 + W, B=B, rz=3.0, ry=2.0, t=(0.2, 0.05, 0.1))
+    gen = torch.Generator().manual_seed(5)
+    dsrc = s["depth"] + 0.1 * torch.rand(s["depth"].shape, generator=gen)
+    it = s["depth"] + 0.05 * torch.rand(s["depth"].shape, generator=gen)
+    is_ = dsrc + 0.05 * torch.rand(s["depth"].shape, generator=gen)
+    wp, wr = 1.3, 0.07
+    dc, dsc = s["depth"].clone().requires_grad_(True), dsrc.clone().requires_grad_(True)
+    synth, valid, grid = warp_loss.inverse_warp(dc, s["src"].permute(0, 3, 1, 2), s["K"], s["invK"], s["T"], pad)
+    lp, _ = warp_loss.masked_photometric_mean(synth, s["tgt"].permute(0, 3, 1, 2), valid)
+    tot = wp * lp
+    if reg:
+        lr = warp_loss.depth_regularizer(it, dc, reg) + warp_loss.depth_regularizer(is_, dsc, reg)
+        tot = tot + wr * lr
+    tot.backward()
+    if nhwc:
+        src, tgt = s["src"].to(DEV).permute(0, 3, 1, 2), s["tgt"].to(DEV).permute(0, 3, 1, 2)
+    else:
+        src, tgt = s["src"].permute(0, 3, 1, 2).contiguous().to(DEV), s["tgt"].permute(0, 3, 1, 2).contiguous().to(DEV)
+    plan = LossGradPlan(B, H, W, torch.device(DEV), pad, True, reg, wp, wr).bind(
+        s["depth"].to(DEV), dsrc.to(DEV), it.to(DEV), is_.to(DEV), src, tgt, s["K"].to(DEV), s["invK"].to(DEV), s["T"].to(DEV))
+    loss, gdt, gds = plan.step()
+    _close(loss[0], lp, what="photometric")
+    _gdepth_close(gdt, dc.grad, grid, what="g depth_tgt")
+    if reg:
+        _close(loss[1], lr, what="reg")
+        _grad_close(gds, dsc.grad, what="g depth_src")
+    l2, g2, _ = plan.step()
+    assert torch.equal(l2, loss) and torch.equal(g2, gdt)       # bitwise reproducible
