@@ -45,9 +45,20 @@ SIGNATURES = {
     "e2e_warp_photo_lossgrad_workspace_floats": [c_int, c_int, c_int],
     "e2e_warp_photo_lossgrad": [c_fp, c_fp, Strides, c_fp, Strides, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp,
                                 c_f32, c_f32, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "e2e_vertex_normal_maps": [c_fp, c_fp, c_fp, c_f32, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "e2e_vertex_maps_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "e2e_transform_points": [c_fp, c_fp, c_fp, c_i64, c_int, c_fp],
+    "e2e_pf_workspace_bytes": [c_i64, c_int, c_int],
+    "e2e_pf_associate": [c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_f32, c_f32, c_fp, c_i64, c_int, c_int, c_fp],
+    "e2e_pf_table": [c_int, c_i64, c_fp, c_i64, c_int, c_int, c_fp, c_fp, c_fp],
+    "e2e_pf_fuse_append": [c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp],
+    "e2e_knn1_workspace_bytes": [c_i64],
+    "e2e_knn1_fwd": [c_fp, c_i64, c_fp, c_i64, c_fp, c_fp, c_fp, c_fp],
+    "e2e_knn1_bwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_fp, c_fp],
 }
 _RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats": c_i64,
-            "e2e_warp_photo_lossgrad_workspace_floats": c_i64}
+            "e2e_warp_photo_lossgrad_workspace_floats": c_i64, "e2e_pf_workspace_bytes": c_i64,
+            "e2e_knn1_workspace_bytes": c_i64}
 
 _lib = None
 

@@ -242,3 +242,119 @@ def warp_photometric(depth_tgt, src, tgt, K, inv_K, T, padding_mode="border", us
     p, r, synth, valid, pmap = _WarpPhotometric.apply(depth_tgt, depth_src, init_tgt, init_src, src, tgt, K, inv_K, T,
                                                       _padding(padding_mode), bool(use_mask), rk, bool(want_pmap))
     return {"photometric": p, "reg": r, "synth": synth, "valid": valid, "pmap": pmap}
+
+
+# ---------------------------------------------------------------------------------------------
+# RGB-D unprojection, rigid transforms, nearest neighbours
+# ---------------------------------------------------------------------------------------------
+def fusion_alpha_den(sigma, eps=1e-7):
+    """2 sigma^2 + eps evaluated in double, rounded to fp32 when passed (gradslam get_alpha)."""
+    return 2.0 * (float(sigma) ** 2) + eps
+
+
+class _VertexMaps(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, K, pose, alpha_den):
+        B, H, W = depth.shape
+        d = L.dev(depth, "depth").contiguous()
+        K, pose = _mat(K, "intrinsics", B), _mat(pose, "poses", B)
+        f = dict(device=d.device, dtype=torch.float32)
+        V, Nm, Vg, Ng = (torch.empty(B, H, W, 3, **f) for _ in range(4))
+        alpha = torch.empty(B, H, W, **f)
+        L.call("e2e_vertex_normal_maps", L.ptr(d), L.ptr(K), L.ptr(pose), float(alpha_den), L.ptr(V), L.ptr(Nm), L.ptr(Vg), L.ptr(Ng),
+               L.ptr(alpha), B, H, W, L.stream())
+        ctx.save_for_backward(d, K, pose)
+        ctx.mark_non_differentiable(Nm, Ng, alpha)
+        return V, Nm, Vg, Ng, alpha
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gV, gN, gVg, gNg, ga):
+        d, K, pose = ctx.saved_tensors
+        B, H, W = d.shape
+        if gV is None and gVg is None:
+            return None, None, None, None
+        gV = gV.contiguous() if gV is not None else None
+        gVg = gVg.contiguous() if gVg is not None else None
+        gd = torch.empty_like(d)
+        L.call("e2e_vertex_maps_bwd", L.ptr(d), L.ptr(K), L.ptr(pose), L.ptr(gV), L.ptr(gVg), L.ptr(gd), B, H, W, L.stream())
+        return gd, None, None, None
+
+
+def vertex_normal_maps(depth, K, pose, sigma=0.6):
+    """depth (B,H,W), K/pose (B,4,4) -> dict V, n, Vg, ng (B,H,W,3), alpha (B,H,W), valid (B,H,W) bool.
+    gradslam RGBDImages maps; differentiable wrt depth through V and Vg."""
+    if depth.dim() != 3:
+        raise ValueError(f"depth: expected (B,H,W), got {tuple(depth.shape)}")
+    V, Nm, Vg, Ng, alpha = _VertexMaps.apply(depth, K, pose, fusion_alpha_den(sigma))
+    return {"V": V, "n": Nm, "Vg": Vg, "ng": Ng, "alpha": alpha, "valid": depth.detach() != 0}
+
+
+class _TransformPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, T):
+        p = L.dev(points, "points").contiguous()
+        T = L.dev(T, "transform").contiguous()
+        out = torch.empty_like(p)
+        L.call("e2e_transform_points", L.ptr(p), L.ptr(T), L.ptr(out), p.shape[0], 0, L.stream())
+        ctx.save_for_backward(T)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        T, = ctx.saved_tensors
+        g = g.contiguous()
+        gp = torch.empty_like(g)
+        L.call("e2e_transform_points", L.ptr(g), L.ptr(T), L.ptr(gp), g.shape[0], 1, L.stream())
+        return gp, None
+
+
+def transform_points(points, T):
+    """gradslam.geometry.geometryutils.transform_pointcloud: (N,3), (4,4) -> (N,3)."""
+    if not torch.is_tensor(points) or not torch.is_tensor(T):
+        raise TypeError("Expected torch.Tensor inputs")
+    if points.dim() != 2 or points.shape[1] != 3:
+        raise ValueError(f"pointcloud must have shape (N,3), got {tuple(points.shape)}")
+    if tuple(T.shape) != (4, 4):
+        raise ValueError(f"transform must have shape (4,4), got {tuple(T.shape)}")
+    if points.shape[0] == 0:
+        return points.clone()
+    return _TransformPoints.apply(points, T)
+
+
+class _Knn1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p1, p2):
+        a, b = L.dev(p1, "p1").contiguous(), L.dev(p2, "p2").contiguous()
+        n1, n2 = a.shape[0], b.shape[0]
+        d = torch.empty(n1, device=a.device, dtype=torch.float32)
+        idx = torch.empty(n1, device=a.device, dtype=torch.int64)
+        ws = torch.empty(L.load().e2e_knn1_workspace_bytes(n1), device=a.device, dtype=torch.uint8)
+        L.call("e2e_knn1_fwd", L.ptr(a), n1, L.ptr(b), n2, L.ptr(d), L.ptr(idx), L.ptr(ws), L.stream())
+        ctx.save_for_backward(a, b, idx)
+        ctx.mark_non_differentiable(idx)
+        return d, idx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gd, _gi):
+        a, b, idx = ctx.saved_tensors
+        gd = gd.contiguous()
+        gp = torch.empty_like(a)
+        L.call("e2e_knn1_bwd", L.ptr(gd), L.ptr(a), L.ptr(b), L.ptr(idx), a.shape[0], L.ptr(gp), L.stream())
+        return gp, None
+
+
+def knn1(p1, p2):
+    """K=1 nearest neighbour of every row of p1 (P1,3) among p2 (P2,3): (squared dists (P1,), idx (P1,) int64).
+    Differentiable wrt p1 (d/dp1 = 2 g (p1 - p2[idx])); p2 is treated as data (the reference detaches it,
+    online_adaption.py:643)."""
+    for n, t in (("p1", p1), ("p2", p2)):
+        if t.dim() != 2 or t.shape[1] != 3:
+            raise ValueError(f"{n}: expected (P,3), got {tuple(t.shape)}")
+    if p2.requires_grad:
+        raise NotImplementedError("gradient wrt the reference cloud (p2) is not on the reference path; detach it")
+    if p1.shape[0] == 0 or p2.shape[0] == 0:
+        raise ValueError("knn1: empty point cloud")
+    return _Knn1.apply(p1, p2)

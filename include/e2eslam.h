@@ -150,6 +150,66 @@ int e2e_warp_photo_lossgrad(const float* depth_tgt, const float* src, e2e_stride
                             float* g_depth_tgt, float* g_depth_src, float* workspace, int B, int H,
                             int W, void* stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* RGB-D unprojection and the PointFusion map step -- gradslam (un-vendored dependency; semantics */
+/* per SURVEY.md Appendix A), reference call sites online_adaption.py:347-363, :461-469, :642      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* gradslam RGBDImages.vertex_map / normal_map / global_vertex_map / global_normal_map and the
+ * fusion confidence alpha = exp(-|V|^2 / alpha_den) (alpha_den = 2 sigma^2 + 1e-7) in one pass.
+ * depth (B,H,W); K, pose (B,4,4); outputs channels-last (B,H,W,3) / alpha (B,H,W).
+ * V, Nm, Ng, alpha may be NULL.  Invalid (zero) depth gives zero rows. */
+int e2e_vertex_normal_maps(const float* depth, const float* K, const float* pose, float alpha_den,
+                           float* V, float* Nm, float* Vg, float* Ng, float* alpha, int B, int H,
+                           int W, void* stream);
+/* d/d(depth) of sum(g_V . V) + sum(g_Vg . Vg); either gradient may be NULL.  The normal map is not
+ * differentiated (nothing on the reference path takes its gradient). */
+int e2e_vertex_maps_bwd(const float* depth, const float* K, const float* pose, const float* g_V,
+                        const float* g_Vg, float* g_depth, int B, int H, int W, void* stream);
+
+/* gradslam.geometry.geometryutils.transform_pointcloud (online_adaption.py:642): out = R p + t for
+ * (n,3) points, T (4,4).  transpose_rotation_only=1 gives R^T p (its autograd wrt the points). */
+int e2e_transform_points(const float* points, const float* T, float* out, int64_t n,
+                         int transpose_rotation_only, void* stream);
+
+/* PointFusion map step (gradslam update_map_fusion) for ONE live frame against ONE resident map.
+ * The map is four capacity-sized arrays (points/normals/colors (cap,3), ccounts (cap)) of which
+ * the first M rows are live.  workspace: e2e_pf_workspace_bytes(cap, H, W) bytes.
+ *
+ * e2e_pf_associate = find_active_map_points + find_similar_map_points +
+ *   find_best_unique_correspondences: per map point the pixel it projects to and its flags, per
+ *   pixel the winning map point (max confidence, then min distance, then min index).
+ * e2e_pf_table materialises one of the three index tables as int64 rows [n, h, w]
+ *   (which = 0 active (ascending n), 1 similar (ascending n), 2 unique (ordered by pixel)); the row
+ *   count goes to *count_out (device int64).  rows must hold min(M, H*W) resp. M rows.
+ * e2e_pf_fuse_append = fuse_with_map: confidence-weighted merge of the matched points, then the
+ *   frame's unmatched valid pixels are appended in row-major order; *new_count_out (device int64)
+ *   receives the new live row count (rows beyond capacity are dropped -- size the map for the run). */
+int64_t e2e_pf_workspace_bytes(int64_t map_capacity, int H, int W);
+int e2e_pf_associate(const float* map_points, const float* map_normals, const float* map_ccounts,
+                     int64_t M, const float* K, const float* pose, const float* Vg, const float* Ng,
+                     float dist_th, float dot_th, void* workspace, int64_t map_capacity, int H, int W,
+                     void* stream);
+int e2e_pf_table(int which, int64_t M, void* workspace, int64_t map_capacity, int H, int W,
+                 long long* rows, long long* count_out, void* stream);
+int e2e_pf_fuse_append(float* map_points, float* map_normals, float* map_colors, float* map_ccounts,
+                       int64_t M, int64_t map_capacity, const float* depth, const float* Vg,
+                       const float* Ng, const float* rgb, const float* alpha, void* workspace, int H,
+                       int W, long long* new_count_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* chamferdist.knn_points, K = 1, D = 3 (loss/losses.py:3,57)                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* p1 (n1,3) queries, p2 (n2,3) references -> dists (n1) squared L2, idx (n1) int64 (first minimum
+ * wins).  workspace: e2e_knn1_workspace_bytes(n1) bytes. */
+int64_t e2e_knn1_workspace_bytes(int64_t n1);
+int e2e_knn1_fwd(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists,
+                 long long* idx, void* workspace, void* stream);
+/* g_p1 = 2 g_dists (p1 - p2[idx]) */
+int e2e_knn1_bwd(const float* g_dists, const float* p1, const float* p2, const long long* idx,
+                 int64_t n1, float* g_p1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
