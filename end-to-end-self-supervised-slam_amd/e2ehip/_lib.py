@@ -55,10 +55,21 @@ SIGNATURES = {
     "e2e_knn1_workspace_bytes": [c_i64],
     "e2e_knn1_fwd": [c_fp, c_i64, c_fp, c_i64, c_fp, c_fp, c_fp, c_fp],
     "e2e_knn1_bwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_fp, c_fp],
+    "e2e_median_workspace_bytes": [],
+    "e2e_median_lower": [c_fp, c_i64, c_fp, c_fp, c_fp],
+    "e2e_depth_scale_workspace_bytes": [],
+    "e2e_depth_scale_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp],
+    "e2e_depth_scale_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp],
+    "e2e_reduce_workspace_floats": [],
+    "e2e_mean_diff_fwd": [c_fp, c_fp, c_i64, c_int, c_fp, c_fp, c_fp],
+    "e2e_mean_diff_bwd": [c_fp, c_fp, c_fp, c_i64, c_int, c_fp, c_fp],
+    "e2e_depth_metrics": [c_fp, c_fp, c_i64, c_int, c_fp, c_fp, c_fp],
+    "e2e_adam_step": [c_fp, c_fp, c_fp, c_fp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_fp],
 }
 _RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats": c_i64,
             "e2e_warp_photo_lossgrad_workspace_floats": c_i64, "e2e_pf_workspace_bytes": c_i64,
-            "e2e_knn1_workspace_bytes": c_i64}
+            "e2e_knn1_workspace_bytes": c_i64, "e2e_median_workspace_bytes": c_i64,
+            "e2e_depth_scale_workspace_bytes": c_i64, "e2e_reduce_workspace_floats": c_i64}
 
 _lib = None
 

@@ -358,3 +358,90 @@ def knn1(p1, p2):
     if p1.shape[0] == 0 or p2.shape[0] == 0:
         raise ValueError("knn1: empty point cloud")
     return _Knn1.apply(p1, p2)
+
+
+# ---------------------------------------------------------------------------------------------
+# median scaling chain, regulariser, metrics
+# ---------------------------------------------------------------------------------------------
+def median_lower(x):
+    """torch.median(x) over all elements (lower median) -> 0-dim device tensor."""
+    x = L.dev(x, "x").contiguous()
+    out = torch.empty((), device=x.device, dtype=torch.float32)
+    ws = torch.empty(L.load().e2e_median_workspace_bytes(), device=x.device, dtype=torch.uint8)
+    L.call("e2e_median_lower", L.ptr(x), x.numel(), L.ptr(out), L.ptr(ws), L.stream())
+    return out
+
+
+class _DepthScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, median_gt):
+        d = L.dev(disp, "disp").contiguous()
+        mg = L.dev(median_gt, "median_gt").reshape(1).contiguous()
+        n = d.numel()
+        delta, depth = torch.empty_like(d), torch.empty_like(d)
+        md = torch.empty(1, device=d.device, dtype=torch.float32)
+        ratio = torch.empty(1, device=d.device, dtype=torch.float32)
+        ws = torch.empty(L.load().e2e_depth_scale_workspace_bytes(), device=d.device, dtype=torch.uint8)
+        L.call("e2e_depth_scale_fwd", L.ptr(d), L.ptr(mg), L.ptr(delta), L.ptr(depth), L.ptr(md), L.ptr(ratio), L.ptr(ws), n, L.stream())
+        ctx.save_for_backward(delta, mg, md, ws)
+        ctx.mark_non_differentiable(delta, ratio)
+        return depth, delta, ratio.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_depth, _gd, _gr):
+        delta, mg, md, ws = ctx.saved_tensors
+        g = g_depth.contiguous()
+        g_disp = torch.empty_like(delta)
+        L.call("e2e_depth_scale_bwd", L.ptr(g), L.ptr(delta), L.ptr(mg), L.ptr(md), L.ptr(g_disp), L.ptr(ws), delta.numel(), L.stream())
+        return g_disp, None
+
+
+def depth_from_disp_median_scaled(disp, median_gt):
+    """disp (F,1,H,W) of the keyframe pair -> (depth = (median_gt / median(1/disp)) / disp, unscaled 1/disp, ratio).
+    The ratio stays inside the autograd graph exactly as in online_adaption.py:292-298 (the in-place `*= ratio`)."""
+    return _DepthScale.apply(disp, median_gt)
+
+
+class _MeanDiff(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, kind):
+        a, b = L.dev(a, "initial_depth").contiguous(), L.dev(b, "refined_depth").contiguous()
+        out = torch.empty(1, device=a.device, dtype=torch.float32)
+        ws = torch.empty(L.load().e2e_reduce_workspace_floats(), device=a.device, dtype=torch.float32)
+        L.call("e2e_mean_diff_fwd", L.ptr(a), L.ptr(b), a.numel(), kind, L.ptr(out), L.ptr(ws), L.stream())
+        ctx.save_for_backward(a, b)
+        ctx.kind = kind
+        return out.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        gb = torch.empty_like(b)
+        L.call("e2e_mean_diff_bwd", L.ptr(a), L.ptr(b), L.ptr(g.reshape(1).contiguous()), a.numel(), ctx.kind, L.ptr(gb), L.stream())
+        return None, gb, None
+
+
+def mean_diff(initial, refined, kind):
+    """mean |initial - refined| ("l1") or mean (initial - refined)^2 ("l2"); gradient flows to `refined` only
+    (the initial depth is a detached clone: online_adaption.py:284-285)."""
+    k = {"l1": 1, "l2": 2}.get(kind)
+    if k is None:
+        raise ValueError("please specify a correct norm")
+    if initial.shape != refined.shape:
+        raise ValueError("shape mismatch")
+    if initial.requires_grad:
+        raise NotImplementedError("gradient wrt the initial depth is not on the reference path")
+    return _MeanDiff.apply(initial, refined, k)
+
+
+def depth_metrics(gt, pred, mask_zero_gt):
+    """-> (7,) device tensor: abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3 (losses.py:162-201)."""
+    gt, pred = L.dev(gt, "gt").contiguous(), L.dev(pred, "pred").contiguous()
+    if gt.numel() != pred.numel():
+        raise ValueError("gt and pred must have the same number of elements")
+    out = torch.empty(7, device=gt.device, dtype=torch.float32)
+    ws = torch.empty(L.load().e2e_reduce_workspace_floats(), device=gt.device, dtype=torch.float32)
+    L.call("e2e_depth_metrics", L.ptr(gt), L.ptr(pred), gt.numel(), int(bool(mask_zero_gt)), L.ptr(out), L.ptr(ws), L.stream())
+    return out

@@ -1,0 +1,81 @@
+"""Fused multi-tensor Adam: every parameter (and its gradient and moments) lives in ONE flat fp32 buffer, so a
+step is a single streaming kernel over 4 arrays and the data-parallel gradient exchange is a single RCCL
+all-reduce of one contiguous 57 MB bucket (no per-tensor launches, no flatten/unflatten copies)."""
+import torch
+
+from . import _lib as L
+
+
+class FlatParams:
+    """Re-homes a list of parameters into one contiguous, 16-byte aligned buffer (params become views) and keeps
+    a matching flat gradient buffer whose slices are installed as `.grad`."""
+
+    def __init__(self, params):
+        params = [p for p in params]
+        if not params:
+            raise ValueError("no parameters")
+        dev = params[0].device
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4            # keep every slice 16-byte aligned
+        self.params, self.offsets, self.numel = params, offs, total
+        self.data = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                self.data[o:o + p.numel()].copy_(p.reshape(-1))
+                p.data = self.data[o:o + p.numel()].view_as(p)
+        self.bind_grads()
+
+    def bind_grads(self):
+        for p, o in zip(self.params, self.offsets):
+            p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        self.bind_grads()
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) semantics (the reference's optimiser:
+    utils/training_utils.py:23-25) in one HIP launch.  Like torch, parameters whose gradient never appears
+    are not moved: a parameter is only updated from the first step in which its gradient slice is non-None,
+    and frozen parameters (requires_grad False) are skipped -- both are handled by an `active` mask folded
+    into the flat layout (inactive parameters are simply left out of the flat buffer)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._all = params
+        self.flat = None
+        self.steps = 0
+
+    def _build(self):
+        # parameters that take part: trainable AND with a gradient at the first step (torch skips grad None)
+        act = [p for p in self._all if p.requires_grad and p.grad is not None]
+        if not act:
+            raise RuntimeError("FusedAdam.step(): no parameter has a gradient")
+        grads = [p.grad.detach().clone() for p in act]
+        self.flat = FlatParams(act)
+        with torch.no_grad():
+            for p, g in zip(act, grads):
+                p.grad.copy_(g)
+        self.m = torch.zeros_like(self.flat.data)
+        self.v = torch.zeros_like(self.flat.data)
+
+    def zero_grad(self, set_to_none=True):
+        if self.flat is None:
+            for p in self._all:
+                p.grad = None
+        else:
+            self.flat.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if self.flat is None:
+            self._build()
+        g = self.param_groups[0]
+        self.steps += 1
+        L.call("e2e_adam_step", L.ptr(self.flat.data), L.ptr(self.flat.grad), L.ptr(self.m), L.ptr(self.v), self.flat.numel,
+               float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self.steps, L.stream())

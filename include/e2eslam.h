@@ -210,6 +210,49 @@ int e2e_knn1_fwd(const float* p1, int64_t n1, const float* p2, int64_t n2, float
 int e2e_knn1_bwd(const float* g_dists, const float* p1, const float* p2, const long long* idx,
                  int64_t n1, float* g_p1, void* stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* disp -> depth, median scaling, regulariser, metrics, optimiser                                */
+/* ------------------------------------------------------------------------------------------ */
+
+/* torch.median over all elements (online_adaption.py:295,343): the LOWER median (rank (n-1)/2) by
+ * radix select; *value_out (device).  workspace: e2e_median_workspace_bytes() bytes; afterwards it
+ * also holds the smallest index whose value equals the median (used by the scale chain's autograd). */
+int64_t e2e_median_workspace_bytes(void);
+int e2e_median_lower(const float* x, int64_t n, float* value_out, void* workspace, void* stream);
+
+/* online_adaption.py:282,292-298 for the n = F*H*W elements of the stacked disparities:
+ *   delta = 1/disp ; ratio = median_gt / median(delta) ; depth = ratio * delta.
+ * median_gt, median_delta, ratio_out are device scalars.  The backward is the exact autograd chain,
+ * including the term torch routes to the element that IS the median:
+ *   g_delta = ratio*g + [i==k*] * (-(ratio/median_delta) * sum(g*delta)) ; g_disp = -delta^2 g_delta.
+ * workspace (shared by fwd and bwd of one step): e2e_depth_scale_workspace_bytes() bytes. */
+int64_t e2e_depth_scale_workspace_bytes(void);
+int e2e_depth_scale_fwd(const float* disp, const float* median_gt, float* delta, float* depth,
+                        float* median_delta, float* ratio_out, void* workspace, int64_t n,
+                        void* stream);
+int e2e_depth_scale_bwd(const float* g_depth, const float* delta, const float* median_gt,
+                        const float* median_delta, float* g_disp, void* workspace, int64_t n,
+                        void* stream);
+
+/* depth_reguralizer (losses.py:134-148) as a stand-alone op: out = mean |a-b| (kind 1) or
+ * mean (a-b)^2 (kind 2); backward wrt b with upstream device scalar g_out.
+ * workspace: e2e_reduce_workspace_floats() floats. */
+int64_t e2e_reduce_workspace_floats(void);
+int e2e_mean_diff_fwd(const float* a, const float* b, int64_t n, int kind, float* out,
+                      float* workspace, void* stream);
+int e2e_mean_diff_bwd(const float* a, const float* b, const float* g_out, int64_t n, int kind,
+                      float* g_b, void* stream);
+
+/* depth_metrics / compute_depth_errors (losses.py:162-201): out7 = abs_rel, sq_rel, rmse, rmse_log,
+ * a1, a2, a3 over the kept pixels (mask_zero_gt = 1 drops gt == 0: the "TUM" rule). */
+int e2e_depth_metrics(const float* gt, const float* pred, int64_t n, int mask_zero_gt, float* out7,
+                      float* workspace, void* stream);
+
+/* torch.optim.Adam step (training_utils.py:23-25; amsgrad off, no weight decay) over ONE flat,
+ * 16-byte-aligned fp32 buffer per state; `step` is the 1-based step count. */
+int e2e_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
