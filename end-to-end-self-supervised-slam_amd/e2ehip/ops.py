@@ -384,8 +384,9 @@ class _DepthScale(torch.autograd.Function):
         ws = torch.empty(L.load().e2e_depth_scale_workspace_bytes(), device=d.device, dtype=torch.uint8)
         L.call("e2e_depth_scale_fwd", L.ptr(d), L.ptr(mg), L.ptr(delta), L.ptr(depth), L.ptr(md), L.ptr(ratio), L.ptr(ws), n, L.stream())
         ctx.save_for_backward(delta, mg, md, ws)
+        ratio = ratio.reshape(())
         ctx.mark_non_differentiable(delta, ratio)
-        return depth, delta, ratio.reshape(())
+        return depth, delta, ratio
 
     @staticmethod
     @once_differentiable

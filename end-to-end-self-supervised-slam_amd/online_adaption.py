@@ -1,0 +1,237 @@
+"""MI355X counterpart of the reference's final system, online_adaption.py: online depth refinement on keyframe
+pairs + PointFusion mapping, same class / method names and the same order of operations, but launched the
+MI355X way:
+
+  * the keyframe pair goes through the depth network as ONE batch of two (BN is in eval mode);
+  * 1/disp, the median ratio and its autograd chain are the e2e_depth_scale_* kernels;
+  * warp + mask + SSIM/L1 + depth regulariser, forward AND backward, are ONE launch (e2e_warp_photo_lossgrad)
+    whose d(loss)/d(depth) is injected into the network's backward -- synth / valid / loss map never reach HBM;
+  * the 3-D loss is unproject -> rigid transform -> exact nearest neighbour (HIP kernels) on the resident map;
+  * Adam is one fused launch over one flat parameter bucket, which is also the single RCCL all-reduce bucket when
+    several GPUs refine several sequences (one sequence per rank);
+  * the global map is a resident e2ehip.FusionMap updated in place.
+
+reference: online_adaption.py:39-57 (SLAM.__init__), :98-155 (model_init), :175-205, :207-257 (main),
+:259-327 (refinement), :329-366 (create_refined_pointcloud), :369-645 (losses).
+
+    python online_adaption.py --config_path configs/config_synthetic.yaml
+"""
+import os
+import sys
+from collections import OrderedDict
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+
+from depth_estimation.networks import DispResNet_Indoor  # noqa: E402
+from e2ehip import dist as edist  # noqa: E402
+from e2ehip import ops  # noqa: E402
+from e2ehip.fused import LossGradPlan  # noqa: E402
+from e2ehip.fusionmap import FusionMap  # noqa: E402
+from e2ehip.synthetic import make_sequence  # noqa: E402
+from utils.training_utils import define_optim, define_schedular, torch_poses_to_transforms  # noqa: E402
+from utils.yaml_configs import load_yaml  # noqa: E402
+
+
+class SLAM:
+    def __init__(self, arguments, sequence=None, state_dict=None):
+        """arguments: the reference's config tree (configs/config.yaml).  sequence: optional pre-loaded
+        (colors 0-1 (1,L,H,W,3), depths (1,L,H,W,1), intrinsics (1,1,4,4), poses (1,L,4,4)); default: synthetic."""
+        self.args = arguments
+        if self.args.SETTINGS.device != "cuda":
+            raise RuntimeError("this implementation runs on the MI355X only (SETTINGS.device: cuda); there is no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.sequence_length = self.args.DEMO.sequence_length
+        self._sequence, self._state_dict = sequence, state_dict
+        self.dataset_init()
+        self.model_init()
+        self.mean_abs = []
+        self.log = []
+
+    # ------------------------------------------------------------------------------------------------
+    def dataset_init(self):
+        a = self.args
+        if self._sequence is None:
+            if a.DATA.name not in ("ICL", "TUM", "synthetic"):
+                raise ValueError("Dataset Not Found")
+            # ICL / TUM file loaders are the next scope row; a synthetic sequence with the same
+            # tensor contract stands in (colours already in [0,1], i.e. after the reference's `colors /= 255`).
+            self._sequence = make_sequence(self.sequence_length, a.DATA.height, a.DATA.width, seed=int(getattr(a.DATA, "seed", 1234)),
+                                           holes=0.1 if a.DATA.name == "TUM" else 0.0)
+        self.colors, self.gt_depths, self.intrinsics, self.poses = (t.to(self.device).contiguous() for t in self._sequence)
+        _, L, self.H, self.W, _ = self.colors.shape
+        self.sequence_length = min(self.sequence_length, L)
+
+    def model_init(self):
+        a = self.args
+        self.models = {}
+        if a.MODEL.slam != "PointFusion":
+            raise NotImplementedError("MODEL.slam: only PointFusion is on the online-adaption path")
+        if a.MODEL.odom != "gt":
+            raise NotImplementedError("MODEL.odom: ICP / GradICP odometry is the next scope row (SURVEY.md 8f N1); use gt")
+        if a.MODEL.depth_network != "indoor":
+            raise ValueError("Given {} is not a valid depth network option".format(a.MODEL.depth_network))
+        self.models["depth"] = DispResNet_Indoor(num_layers=a.MODEL.num_layers, pretrained=a.MODEL.weights_init_encoder == "imagenet")
+        if self._state_dict is not None:
+            self.models["depth"].load_state_dict(self._state_dict)
+        elif a.MODEL.use_pretrained_models:
+            self.load_model_indoor()
+        self.models["depth"].to(self.device)
+        self.train_params = list(self.models["depth"].parameters())
+        self.optimizer = define_optim(a, self.train_params)
+        self.schedular = define_schedular(a, self.optimizer)
+        cap = int(getattr(a.MODEL, "map_capacity", 0)) or (self.sequence_length + 1) * self.H * self.W
+        self.map = FusionMap(cap, self.H, self.W, self.device, a.MODEL.dist_th, a.MODEL.angle_th, a.MODEL.sigma)
+        reg = a.LOSS.depth_regularizer_type if a.LOSS.depth_regularizer else None
+        self.plan = LossGradPlan(1, self.H, self.W, self.device, a.MODEL.padding_mode, a.LOSS.photometric_mask, reg,
+                                 1.0, a.LOSS.depth_regularizer_weight if reg else 0.0)
+        for flag in ("geometric", "smoothness", "supervise_depth", "auto_masking", "min_reprojection"):
+            if getattr(a.LOSS, flag):
+                raise NotImplementedError(f"LOSS.{flag} is off in the reference's recommended configuration and is a next scope row (SURVEY.md 8f N3)")
+
+    def load_model_indoor(self):
+        path = os.path.join(os.path.expanduser(self.args.MODEL.load_depth_path), "depth.pth.tar")
+        assert os.path.isfile(path), "Cannot find {}".format(path)
+        self.models["depth"].load_state_dict(torch.load(path, map_location="cpu")["state_dict"])
+
+    def set_refinement_mode(self):
+        """eval mode everywhere + freeze every parameter whose NAME contains "bn" (online_adaption.py:175-184)."""
+        for m in self.models.values():
+            m.eval()
+            for name, p in m.named_parameters():
+                if name.find("bn") != -1:
+                    p.requires_grad = False
+
+    @staticmethod
+    def compute_frame_distance(prev, cur):
+        """distance between the camera centres -R^T t of two (1,4,4) extrinsics (online_adaption.py:186-205)."""
+        pc = -1 * torch.matmul(prev[0, :3, :3].transpose(0, 1), prev[0, :3, -1])
+        cc = -1 * torch.matmul(cur[0, :3, :3].transpose(0, 1), cur[0, :3, -1])
+        return torch.linalg.norm(pc - cc)
+
+    # ------------------------------------------------------------------------------------------------
+    def main(self):
+        if self.args.MODEL.refinement_mode:
+            self.set_refinement_mode()
+        prev = 0
+        self.first_iter = True
+        # keyframe schedule decided once on the host (poses are data, not results): no device sync per frame
+        poses_h = self.poses.cpu()
+        for frame in range(1, self.sequence_length):
+            if self.compute_frame_distance(poses_h[:, prev], poses_h[:, frame]) > self.args.DEMO.frame_threshold:
+                self.refinement(prev, frame)
+                self.first_iter = False
+                prev = frame
+        if self.args.DEBUG.print_metrics and self.mean_abs:
+            print(torch.tensor(self.mean_abs).mean().item())
+        return self.map
+
+    def _pair(self, prev, cur):
+        idx = torch.tensor([prev, cur], device=self.device)
+        colors = self.colors[:, idx]            # (1,2,H,W,3)
+        gt = self.gt_depths[:, idx]
+        poses = self.poses[:, idx]
+        return colors, gt, poses
+
+    def refinement(self, prev, cur):
+        a = self.args
+        colors, gt, poses = self._pair(prev, cur)
+        transform = torch_poses_to_transforms(poses)
+        K = self.intrinsics[:, 0]
+        inv_K = torch.pinverse(K)
+        T = transform[:, 1].contiguous()
+        median_gt = ops.median_lower(gt)
+        src, tgt = colors[:, 0].permute(0, 3, 1, 2), colors[:, 1].permute(0, 3, 1, 2)     # NHWC memory, NCHW views
+        initial = None
+        use_reg = a.LOSS.depth_regularizer and a.OPTIMIZATION.refinement == "PFT"
+        use_3d = a.LOSS.three3d_loss and not self.first_iter
+        for refine_step in range(a.OPTIMIZATION.refinement_steps):
+            self.optimizer.zero_grad()
+            disp = self.models["depth"](colors[0], 0)[("disp", 0, 0)]                     # (2,1,H,W): pair as one batch
+            depth, delta, ratio = ops.depth_from_disp_median_scaled(disp, median_gt)
+            if refine_step == 0 and use_reg:
+                initial = delta.clone()                                                  # 1/disp BEFORE scaling (:284-285)
+            d_src, d_tgt = depth[0:1], depth[1:2]
+            self.plan.bind(d_tgt.detach(), d_src.detach(), initial[1:2] if use_reg else None, initial[0:1] if use_reg else None,
+                           src, tgt, K, inv_K, T)
+            loss2, g_tgt, g_src = self.plan.step()
+            g_depth = torch.cat([g_src if use_reg else torch.zeros_like(g_tgt), g_tgt], 0)
+            roots, grads = [depth], [g_depth]
+            l3 = None
+            if use_3d:
+                l3 = self.compute_3d_loss(d_tgt, K, poses[:, 1], T)
+                roots.append(l3 * a.LOSS.three3d_loss_weight)
+                grads.append(None)
+            torch.autograd.backward(roots, grads)
+            self._exchange_gradients()
+            self.optimizer.step()
+            if a.DEBUG.print_metrics:
+                m = ops.depth_metrics(gt[0, 1], d_tgt.detach(), a.DATA.name == "TUM")
+                total = loss2[0] + (a.LOSS.depth_regularizer_weight * loss2[1] if use_reg else 0.0)
+                if l3 is not None:
+                    total = total + a.LOSS.three3d_loss_weight * l3.detach()
+                rec = torch.cat([total.reshape(1), loss2, ratio.reshape(1), m, (l3.detach() if l3 is not None else torch.zeros((), device=self.device)).reshape(1)]).cpu()
+                self.log.append(rec)
+                print("Refine_Step:", refine_step, "Total_Loss:", round(rec[0].item(), 5), "abs_rel: ", round(rec[4].item(), 5),
+                      "rmse: ", round(rec[6].item(), 5), "a1: ", round(rec[8].item(), 5))
+                if refine_step == a.OPTIMIZATION.refinement_steps - 1:
+                    self.mean_abs.append(rec[4].item())
+        self.create_refined_pointcloud(colors, gt, poses, median_gt)
+
+    def compute_3d_loss(self, d_tgt, K, pose_tgt, T):
+        """End-2-end point supervision (online_adaption.py:457-471 + :638-645): the target frame's local cloud (in world
+        coordinates through its pose) is transformed AGAIN by T (reference quirk) and pulled
+        towards its nearest neighbours in the detached global map."""
+        maps = ops.vertex_normal_maps(d_tgt.reshape(1, self.H, self.W), K, pose_tgt, self.map.sigma)
+        cloud = maps["Vg"][0][maps["valid"][0]]
+        moved = ops.transform_points(cloud, T[0])
+        d, _ = ops.knn1(moved, self.map.points[: self.map.M])
+        return d.mean()
+
+    def _exchange_gradients(self):
+        if edist.world() > 1:
+            if self.optimizer.flat is None:
+                self.optimizer._build()
+            edist.allreduce_mean_(self.optimizer.flat.grad)
+
+    @torch.no_grad()
+    def create_refined_pointcloud(self, colors, gt, poses, median_gt):
+        disp = self.models["depth"](colors[0], 0)[("disp", 0, 0)]
+        depth, _, _ = ops.depth_from_disp_median_scaled(disp, median_gt)
+        K = self.intrinsics[0, 0]
+        if self.first_iter:
+            self.map.step(colors[0, 0], depth[0, 0], K, poses[0, 0])
+        self.map.step(colors[0, 1], depth[1, 0], K, poses[0, 1])
+        return self.map
+
+
+def default_config(height=480, width=640, sequence_length=60):
+    """The reference's config tree (configs/config.yaml) with the README's online-adaption settings
+    (README.md:146-158: 3 refinement steps, photometric + 3-D + depth regulariser) and odom: gt."""
+    from utils.yaml_configs import _wrap
+    return _wrap(OrderedDict(
+        SETTINGS=dict(name="run", num_workers=0, device="cuda"),
+        DATA=dict(name="synthetic", height=height, width=width, frames=[0, -1], scales=[0], seed=1234),
+        MODEL=dict(depth_network="indoor", num_layers=18, weights_init_encoder=False, use_pretrained_models=False, load_depth_path="",
+                   slam="PointFusion", odom="gt", dist_th=0.05, angle_th=20, sigma=0.6, numiters=20, padding_mode="border",
+                   refinement_mode=True),
+        LOSS=dict(chamfer_distance=False, knn_points=False, auto_masking=False, min_reprojection=False, photometric_mask=True,
+                  geometric=False, geometric_weight=0.5, smoothness=False, smoothness_weight=1e-3, depth_regularizer=True,
+                  depth_regularizer_weight=1e-2, depth_regularizer_type="l2", supervise_depth=False, three3d_loss=True,
+                  three3d_loss_weight=1.0),
+        OPTIMIZATION=dict(batch_size=1, refinement="PFT", refinement_steps=3, learning_rate=1e-5, optimizer="Adam", schedular="StepLR",
+                          schedular_step_size=100, schedular_gamma=0.5),
+        DEBUG=dict(print_metrics=True),
+        DEMO=dict(sequence_length=sequence_length, frame_threshold=0.05),
+    ))
+
+
+if __name__ == "__main__":
+    from utils.arguments import arguments
+    cli = arguments()
+    cfg = load_yaml(cli["config_path"])
+    cfg.SETTINGS.name = cli["name"]
+    SLAM(cfg).main()
