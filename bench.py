@@ -71,6 +71,47 @@ def cpu_baseline(H, W, budget_s=12.0):
             "sample": f"{n} fwd+bwd steps of the same 1x{H}x{W} warp+photometric+reg workload ({el:.1f} s), torch CPU, {cores} threads (best of a short sweep)"}
 
 
+def full_step_bench(a, rank, world, dev):
+    """Whole refinement steps (BASELINE configs[2] shape on a synthetic sequence): per keyframe pair 3 x (network fwd+bwd on the
+    pair, median scale, fused warp/photometric/regulariser, 3-D nearest-neighbour loss against the map, Adam) + the map update."""
+    import torch.distributed as dist
+    from e2ehip.synthetic import make_sequence
+    from online_adaption import SLAM, default_config
+    H, W = a.height, a.width
+    cfg = default_config(H, W, 3)
+    cfg.DEBUG.print_metrics = False
+    cfg.DEMO.frame_threshold = 0.0
+    cfg.MODEL.map_capacity = (8 + 2 * (a.warmup + a.steps)) * H * W
+    slam = SLAM(cfg, sequence=make_sequence(3, H, W, seed=1234 + rank))
+    slam.main()                                   # pairs (0,1), (1,2): builds the map, warms everything up
+    for _ in range(a.warmup):
+        slam.refinement(1, 2)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        slam.refinement(1, 2)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    nsteps = a.steps * cfg.OPTIMIZATION.refinement_steps
+    if rank == 0:
+        from e2ehip import nn_ops
+        print(json.dumps({"metric": "online refinement steps/sec @640x480", "value": world * nsteps / el, "unit": "steps/s", "n_gpus": world,
+                          "steps": nsteps, "warmup": a.warmup * 3, "ms_per_step": 1e3 * el / nsteps, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "full refinement step (depth net fwd+bwd on the pair, median scale, fused warp+photometric+reg, "
+                                                 "3-D KNN loss, Adam; map update every 3rd step)", "height": H, "width": W,
+                                     "conv_backend": "hip" if nn_ops._use_hip(torch.zeros(1, device=dev)) else "miopen-scaffold",
+                                     "map_points": int(slam.map.M)}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +122,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--workload", default="warp", choices=["warp", "full"],
+                    help="warp: BASELINE configs[1] (default). full: whole refinement step incl. depth network, 3-D loss, Adam, map update")
     ap.add_argument("--split", action="store_true", help="two-kernel form (e2e_warp_photo_fwd + _bwd) instead of the single-launch lossgrad")
     a = ap.parse_args()
 
@@ -94,6 +137,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    if a.workload == "full":
+        return full_step_bench(a, rank, world, dev)
     from e2ehip import _lib as L
     from e2ehip.fused import LossGradPlan, WarpPhotoPlan
     from synth import make_pair
