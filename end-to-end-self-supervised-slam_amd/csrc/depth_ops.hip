@@ -30,20 +30,36 @@ struct MedState {
     unsigned int prefix, rank, key, index;
 };
 
-// find the bin that holds rank `r` in hist[0..nb): returns bin, writes rank inside the bin.  One workgroup-wide
-// cooperative scan (all threads call it, result broadcast through LDS).
+// find the bin that holds rank `r` in hist[0..nb) (nb <= 2048): returns the bin, writes the rank inside the bin.
+// Workgroup-cooperative: thread t owns bins [8t, 8t+8); block-wide exclusive scan of the per-thread sums; the one
+// thread whose range contains r resolves the bin.  All threads must call it.  sh: 8 words.
 __device__ unsigned int select_bin(const unsigned int* __restrict__ hist, int nb, unsigned int r, unsigned int* r_in, unsigned int* sh) {
-    // sh: nb + 2 words.  Serial scan by thread 0 over <= 2048 bins is ~2 us; keep it simple and exact.
-    if (threadIdx.x == 0) {
-        unsigned int acc = 0, b = 0;
-        for (int i = 0; i < nb; ++i) {
-            const unsigned int c = hist[i];
-            if (r < acc + c) { b = i; break; }
-            acc += c;
-            b = i;
+    unsigned int c[8], s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = threadIdx.x * 8 + j;
+        c[j] = (i < nb) ? hist[i] : 0u;
+        s += c[j];
+    }
+    unsigned int x = s;                               // inclusive scan across the workgroup (4 waves)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int y = __shfl_up(x, o, 64);
+        if ((threadIdx.x & 63) >= o) x += y;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) sh[2 + (threadIdx.x >> 6)] = x;
+    __syncthreads();
+    unsigned int woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += sh[2 + w];
+    const unsigned int excl = woff + x - s;
+    if (r >= excl && r < excl + s) {                  // exactly one thread (bins are disjoint, total > r)
+        unsigned int acc = excl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (r < acc + c[j]) { sh[0] = threadIdx.x * 8 + j; sh[1] = r - acc; break; }
+            acc += c[j];
         }
-        sh[0] = b;
-        sh[1] = r - acc;
     }
     __syncthreads();
     *r_in = sh[1];
@@ -55,7 +71,7 @@ template <int PASS>
 __global__ __launch_bounds__(DT) void k_median_hist(const float* __restrict__ x, int64_t n, unsigned int rank0,
                                                     unsigned int* __restrict__ hist /* 3 x 2048 */, MedState* __restrict__ st) {
     __shared__ unsigned int lh[MED_BINS];
-    __shared__ unsigned int sh[4];
+    __shared__ unsigned int sh[8];
     for (int i = threadIdx.x; i < MED_BINS; i += DT) lh[i] = 0;
     unsigned int prefix = 0;
     if (PASS == 1) {
@@ -87,7 +103,7 @@ __global__ __launch_bounds__(DT) void k_median_hist(const float* __restrict__ x,
 // final: resolve the last digit, then the smallest index holding that key (torch returns one index of the median)
 __global__ __launch_bounds__(DT) void k_median_final(const float* __restrict__ x, int64_t n, const unsigned int* __restrict__ hist,
                                                      MedState* __restrict__ st, float* __restrict__ value_out) {
-    __shared__ unsigned int sh[4];
+    __shared__ unsigned int sh[8];
     unsigned int rin;
     const unsigned int b2 = select_bin(hist + 2 * MED_BINS, 1024, st->rank, &rin, sh);
     const unsigned int key = st->prefix | b2;
@@ -276,7 +292,9 @@ int e2e_median_lower(const float* x, int64_t n, float* value_out, void* workspac
     unsigned int* hist = (unsigned int*)workspace;
     MedState* ms = (MedState*)(hist + 3 * MED_BINS);
     const unsigned int rank = (unsigned int)((n - 1) / 2);        // torch.median: the LOWER median
-    const int g = sgrid(n, 512);
+    // few workgroups: the histograms of depth data are concentrated in a few dozen bins, and every workgroup's flush
+    // is a same-address device atomic (~0.18 us each, serialised) -- 512 workgroups made these passes 78-111 us
+    const int g = sgrid(n, 96);
     hipLaunchKernelGGL(k_median_init, dim3(1), dim3(256), 0, st, hist, ms);
     hipLaunchKernelGGL(k_median_hist<0>, dim3(g), dim3(DT), 0, st, x, n, rank, hist, ms);
     hipLaunchKernelGGL(k_median_hist<1>, dim3(g), dim3(DT), 0, st, x, n, rank, hist, ms);

@@ -75,15 +75,383 @@ __global__ __launch_bounds__(KT) void k_knn1_bwd(const float* __restrict__ g, co
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Exact uniform-grid acceleration (results identical to the brute force, ties included).
+//   build : bbox (integer atomics on order-preserving keys) -> cell size h = max(extent/GRID_MAX, H_MIN) ->
+//           per-cell counts -> exclusive scan -> counting-sort scatter of (x,y,z,index) float4s
+//   query : one query per lane; visit the cube of radius r cells around the query's cell, shell by shell, keeping
+//           the lexicographic minimum of (distance, index); stop as soon as the best distance is strictly below
+//           the (safety-shrunk) distance to the nearest unexplored face -- nothing outside can tie or win.
+//           Queries still unresolved after radius GRID_RMAX are finished by a brute-force scan (one workgroup
+//           per such query).
+// Intra-cell order after the scatter depends on atomic arrival order, but min over (distance, index) does not.
+// ---------------------------------------------------------------------------------------------
+#define GRID_MAX 128
+#define GRID_CELLS_CAP (GRID_MAX * GRID_MAX * GRID_MAX)
+#define GRID_HMIN 0.02f
+#define GRID_RMAX 6
+#define SCAN_BLOCK 1024
+
+struct GridInfo {
+    unsigned int bb[6];        // order-preserving keys of min xyz, max xyz
+    float origin[3], h, inv_h;
+    int dims[3];
+    unsigned int n_unresolved;
+};
+
+__device__ __forceinline__ unsigned int fkey(float f) {
+    const unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned int k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+__global__ void k_grid_init(GridInfo* gi, unsigned int* counts, unsigned int* fill, int64_t ncell) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= ncell; i += (int64_t)gridDim.x * blockDim.x) {
+        counts[i] = 0;
+        if (i < ncell) fill[i] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        gi->bb[0] = gi->bb[1] = gi->bb[2] = 0xFFFFFFFFu;
+        gi->bb[3] = gi->bb[4] = gi->bb[5] = 0u;
+        gi->n_unresolved = 0;
+    }
+}
+
+// NOTE: device-scope atomics that hit ONE address serialise at the memory side at ~0.18 us each (3072 of them made
+// this kernel 555 us): the workgroups publish their partial boxes instead and k_grid_setup folds them.
+#define BBOX_BLOCKS 256
+__global__ __launch_bounds__(KT) void k_grid_bbox(const float* __restrict__ p, int64_t n, unsigned int* __restrict__ part) {
+    __shared__ unsigned int slo[3][KT / 64], shi[3][KT / 64];
+    unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    for (int64_t i = (int64_t)blockIdx.x * KT + threadIdx.x; i < n; i += (int64_t)gridDim.x * KT)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned int k = fkey(p[i * 3 + c]);
+            lo[c] = min(lo[c], k);
+            hi[c] = max(hi[c], k);
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[c] = min(lo[c], (unsigned int)__shfl_down((int)lo[c], o, 64));
+            hi[c] = max(hi[c], (unsigned int)__shfl_down((int)hi[c], o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { slo[c][threadIdx.x >> 6] = lo[c]; shi[c][threadIdx.x >> 6] = hi[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {                       // one pair of integer atomics per workgroup and axis
+        const int c = threadIdx.x;
+        unsigned int l = slo[c][0], h = shi[c][0];
+        for (int w = 1; w < KT / 64; ++w) { l = min(l, slo[c][w]); h = max(h, shi[c][w]); }
+        part[blockIdx.x * 6 + c] = l;
+        part[blockIdx.x * 6 + 3 + c] = h;
+    }
+}
+
+__global__ __launch_bounds__(BBOX_BLOCKS) void k_grid_setup(GridInfo* gi, const unsigned int* __restrict__ part, int nparts) {
+    __shared__ unsigned int sh[6][BBOX_BLOCKS / 64];
+    for (int c = 0; c < 6; ++c) {
+        unsigned int v = (threadIdx.x < nparts) ? part[threadIdx.x * 6 + c] : (c < 3 ? 0xFFFFFFFFu : 0u);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned int w = (unsigned int)__shfl_down((int)v, o, 64);
+            v = (c < 3) ? min(v, w) : max(v, w);
+        }
+        if ((threadIdx.x & 63) == 0) sh[c][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int c = 0; c < 6; ++c) {
+        unsigned int v = sh[c][0];
+        for (int w = 1; w < BBOX_BLOCKS / 64; ++w) v = (c < 3) ? min(v, sh[c][w]) : max(v, sh[c][w]);
+        gi->bb[c] = v;
+    }
+    float lo[3], ext = 0.f;
+    for (int c = 0; c < 3; ++c) {
+        lo[c] = fkey_inv(gi->bb[c]);
+        ext = fmaxf(ext, fkey_inv(gi->bb[3 + c]) - lo[c]);
+    }
+    const float h = fmaxf(ext / (float)(GRID_MAX - 1), GRID_HMIN);
+    gi->h = h;
+    gi->inv_h = 1.0f / h;
+    for (int c = 0; c < 3; ++c) {
+        gi->origin[c] = lo[c];
+        int d = (int)floorf((fkey_inv(gi->bb[3 + c]) - lo[c]) / h) + 1;
+        gi->dims[c] = min(max(d, 1), GRID_MAX);
+    }
+}
+
+__device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int dim) {
+    return min(max((int)floorf((v - o) * inv_h), 0), dim - 1);
+}
+
+__global__ __launch_bounds__(KT) void k_grid_count(const float* __restrict__ p, int64_t n, const GridInfo* __restrict__ gi,
+                                                   unsigned int* __restrict__ cell_of, unsigned int* __restrict__ counts) {
+    const float ox = gi->origin[0], oy = gi->origin[1], oz = gi->origin[2], ih = gi->inv_h;
+    const int dx = gi->dims[0], dy = gi->dims[1], dz = gi->dims[2];
+    for (int64_t i = (int64_t)blockIdx.x * KT + threadIdx.x; i < n; i += (int64_t)gridDim.x * KT) {
+        const int cx = cell_coord(p[i * 3], ox, ih, dx), cy = cell_coord(p[i * 3 + 1], oy, ih, dy), cz = cell_coord(p[i * 3 + 2], oz, ih, dz);
+        const unsigned int c = (unsigned int)((cz * dy + cy) * dx + cx);
+        cell_of[i] = c;
+        atomicAdd(&counts[c], 1u);
+    }
+}
+
+// three-kernel exclusive scan over ncell+1 counters: block sums -> scan of block sums -> local scan + offset
+__global__ __launch_bounds__(KT) void k_scan_blocksum(const unsigned int* __restrict__ v, int64_t n, unsigned int* __restrict__ bsum) {
+    __shared__ unsigned int sh[KT / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+    unsigned int s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += (base + j < n) ? v[base + j] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(1024) void k_scan_bsums(unsigned int* __restrict__ bsum, int nb) {
+    __shared__ unsigned int wsum[16];
+    __shared__ unsigned int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const unsigned int v = (i < nb) ? bsum[i] : 0u;
+        unsigned int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int y = __shfl_up(x, o, 64);
+            if ((threadIdx.x & 63) >= o) x += y;
+        }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+        __syncthreads();
+        unsigned int woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+        const unsigned int carry = carry_s;
+        if (i < nb) bsum[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(KT) void k_scan_apply(const unsigned int* __restrict__ v, int64_t n, const unsigned int* __restrict__ bsum,
+                                                   unsigned int* __restrict__ out) {
+    __shared__ unsigned int sh[KT / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+    unsigned int a[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = (base + j < n) ? v[base + j] : 0u; s += a[j]; }
+    unsigned int x = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int y = __shfl_up(x, o, 64);
+        if ((threadIdx.x & 63) >= o) x += y;
+    }
+    if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = x;
+    __syncthreads();
+    unsigned int woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += sh[w];
+    unsigned int run = bsum[blockIdx.x] + woff + x - s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (base + j < n) out[base + j] = run;
+        run += a[j];
+    }
+}
+
+__global__ __launch_bounds__(KT) void k_grid_scatter(const float* __restrict__ p, int64_t n, const unsigned int* __restrict__ cell_of,
+                                                     const unsigned int* __restrict__ starts, unsigned int* __restrict__ fill,
+                                                     float4* __restrict__ sorted) {
+    for (int64_t i = (int64_t)blockIdx.x * KT + threadIdx.x; i < n; i += (int64_t)gridDim.x * KT) {
+        const unsigned int c = cell_of[i];
+        const unsigned int pos = starts[c] + atomicAdd(&fill[c], 1u);
+        sorted[pos] = make_float4(p[i * 3], p[i * 3 + 1], p[i * 3 + 2], __uint_as_float((unsigned int)i));
+    }
+}
+
+__global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1, int64_t n1, GridInfo* __restrict__ gi,
+                                                   const unsigned int* __restrict__ starts, const float4* __restrict__ sorted,
+                                                   float* __restrict__ dists, long long* __restrict__ idx,
+                                                   unsigned int* __restrict__ unresolved) {
+    const int64_t i0 = (int64_t)blockIdx.x * KT + threadIdx.x;
+    const bool live = i0 < n1;
+    const int64_t i = live ? i0 : n1 - 1;                      // idle lanes shadow the last query and write nothing
+    const float x = p1[i * 3], y = p1[i * 3 + 1], z = p1[i * 3 + 2];
+    const float q[3] = {x, y, z};
+    const float h = gi->h, ih = gi->inv_h;
+    const int dims[3] = {gi->dims[0], gi->dims[1], gi->dims[2]};
+    const float org[3] = {gi->origin[0], gi->origin[1], gi->origin[2]};
+    int cq[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cq[c] = cell_coord(q[c], org[c], ih, dims[c]);
+    float bd = 3.402823466e38f;
+    unsigned int bi = 0xFFFFFFFFu;
+    bool done = !live;
+    int pl[3] = {0, 0, 0}, ph[3] = {-1, -1, -1};                  // previously explored cube (empty)
+    for (int r = 0; r <= GRID_RMAX && !done; ++r) {
+        int lo[3], hi[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lo[c] = max(cq[c] - r, 0); hi[c] = min(cq[c] + r, dims[c] - 1); }
+        for (int cz = lo[2]; cz <= hi[2]; ++cz)
+            for (int cy = lo[1]; cy <= hi[1]; ++cy) {
+                // cells of one (cz,cy) row are consecutive => their points form ONE contiguous range of `sorted`.
+                // A row that was already inside the previous cube only contributes its two new end segments.
+                const bool row_in_prev = cz >= pl[2] && cz <= ph[2] && cy >= pl[1] && cy <= ph[1];
+                const unsigned int rowbase = (unsigned int)((cz * dims[1] + cy) * dims[0]);
+                int seg_lo[2] = {lo[0], 0}, seg_hi[2] = {hi[0], -1};
+                if (row_in_prev) { seg_hi[0] = pl[0] - 1; seg_lo[1] = ph[0] + 1; seg_hi[1] = hi[0]; }
+#pragma unroll
+                for (int sgm = 0; sgm < 2; ++sgm) {
+                    if (seg_lo[sgm] > seg_hi[sgm]) continue;
+                    unsigned int k = starts[rowbase + seg_lo[sgm]];
+                    const unsigned int e = starts[rowbase + seg_hi[sgm] + 1];
+                    for (; k + 4 <= e; k += 4) {
+                        float4 t[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) t[u] = sorted[k + u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float dx = x - t[u].x, dy = y - t[u].y, dz = z - t[u].z;
+                            const float d = (dx * dx + dy * dy) + dz * dz;
+                            const unsigned int id = __float_as_uint(t[u].w);
+                            if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
+                        }
+                    }
+                    for (; k < e; ++k) {
+                        const float4 t = sorted[k];
+                        const float dx = x - t.x, dy = y - t.y, dz = z - t.z;
+                        const float d = (dx * dx + dy * dy) + dz * dz;
+                        const unsigned int id = __float_as_uint(t.w);
+                        if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
+                    }
+                }
+            }
+        // lower bound on the distance to any point outside the explored cube
+        float db = 3.402823466e38f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (lo[c] > 0) db = fminf(db, q[c] - (org[c] + (float)lo[c] * h));
+            if (hi[c] < dims[c] - 1) db = fminf(db, (org[c] + (float)(hi[c] + 1) * h) - q[c]);
+        }
+        if (db >= 3.0e38f) done = true;                            // the whole grid has been visited
+        else {
+            const float dbe = db * 0.999f - 1e-5f;                 // points sit in their cell up to fp32 rounding
+            if (dbe > 0.f && bd < dbe * dbe) done = true;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pl[c] = lo[c]; ph[c] = hi[c]; }
+    }
+    if (done && live) {
+        dists[i] = bd;
+        idx[i] = (long long)bi;
+    }
+    // unresolved queries: ONE atomic per wave (ballot + prefix popcount), not one per lane
+    const unsigned long long m = __ballot(!done);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        unsigned int base = 0;
+        if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&gi->n_unresolved, (unsigned int)__builtin_popcountll(m));
+        base = __shfl(base, (int)__builtin_ctzll(m), 64);
+        if (!done) unresolved[base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (unsigned int)i;
+    }
+}
+
+// brute force for the queries the grid could not bound: one workgroup per query
+__global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, const float* __restrict__ p2, int64_t n2,
+                                                  const GridInfo* __restrict__ gi, const unsigned int* __restrict__ unresolved,
+                                                  float* __restrict__ dists, long long* __restrict__ idx) {
+    __shared__ unsigned long long sh[KT / 64];
+    const unsigned int cnt = gi->n_unresolved;
+    for (unsigned int u = blockIdx.x; u < cnt; u += gridDim.x) {
+        const unsigned int i = unresolved[u];
+        const float x = p1[(int64_t)i * 3], y = p1[(int64_t)i * 3 + 1], z = p1[(int64_t)i * 3 + 2];
+        unsigned long long best = 0xFFFFFFFFFFFFFFFFull;
+        for (int64_t j = threadIdx.x; j < n2; j += KT) {
+            const float dx = x - p2[j * 3], dy = y - p2[j * 3 + 1], dz = z - p2[j * 3 + 2];
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)j;
+            best = (key < best) ? key : best;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_down(best, o, 64);
+            best = (other < best) ? other : best;
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < KT / 64; ++w) best = (sh[w] < best) ? sh[w] : best;
+            dists[i] = __uint_as_float((unsigned int)(best >> 32));
+            idx[i] = (long long)(best & 0xFFFFFFFFull);
+        }
+    }
+}
+
 extern "C" {
 
-int64_t e2e_knn1_workspace_bytes(int64_t n1) { return n1 > 0 ? 8 * n1 : 0; }
+static int knn1_brute(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists, long long* idx, void* workspace, hipStream_t st);
+#define KNN_GRID_MIN_N2 8192      // below this the brute force is already cheap
+
+static int64_t grid_ws_bytes(int64_t n1, int64_t n2) {
+    const int64_t nc = GRID_CELLS_CAP, nb = (nc + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    // GridInfo | counts[nc+1] | starts[nc+1] | fill[nc] | bsum[nb] | cell_of[n2] | unresolved[n1] | sorted float4[n2]
+    return 256 + 4 * (nc + 1) * 2 + 4 * nc + 4 * (nb + 1) + 4 * 6 * BBOX_BLOCKS + 4 * n2 + 4 * n1 + 64 + 16 * n2;
+}
+
+int64_t e2e_knn1_workspace_bytes(int64_t n1, int64_t n2) {
+    if (n1 <= 0 || n2 <= 0) return 0;
+    // sized for EITHER algorithm (the caller may force the grid on a small set)
+    const int64_t brute = 8 * n1, grid = grid_ws_bytes(n1, n2);
+    return brute > grid ? brute : grid;
+}
+
+static int knn1_grid(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists, long long* idx, void* workspace, hipStream_t st) {
+    const int64_t nc = GRID_CELLS_CAP, nscan = nc + 1;
+    const int nb = (int)((nscan + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    char* w = (char*)workspace;
+    GridInfo* gi = (GridInfo*)w; w += 256;
+    unsigned int* counts = (unsigned int*)w; w += 4 * (nc + 1);
+    unsigned int* starts = (unsigned int*)w; w += 4 * (nc + 1);
+    unsigned int* fill = (unsigned int*)w; w += 4 * nc;
+    unsigned int* bsum = (unsigned int*)w; w += 4 * (nb + 1);
+    unsigned int* bbpart = (unsigned int*)w; w += 4 * 6 * BBOX_BLOCKS;
+    unsigned int* cell_of = (unsigned int*)w; w += 4 * n2;
+    unsigned int* unresolved = (unsigned int*)w; w += 4 * n1;
+    w = (char*)(((uintptr_t)w + 63) & ~(uintptr_t)63);
+    float4* sorted = (float4*)w;
+    const int gp = (int)((n2 + KT - 1) / KT > 2048 ? 2048 : (n2 + KT - 1) / KT);
+    hipLaunchKernelGGL(k_grid_init, dim3(2048), dim3(256), 0, st, gi, counts, fill, nc);
+    const int bb_blocks = gp > BBOX_BLOCKS ? BBOX_BLOCKS : gp;
+    hipLaunchKernelGGL(k_grid_bbox, dim3(bb_blocks), dim3(KT), 0, st, p2, n2, bbpart);
+    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(BBOX_BLOCKS), 0, st, gi, bbpart, bb_blocks);
+    hipLaunchKernelGGL(k_grid_count, dim3(gp), dim3(KT), 0, st, p2, n2, gi, cell_of, counts);
+    hipLaunchKernelGGL(k_scan_blocksum, dim3(nb), dim3(KT), 0, st, counts, nscan, bsum);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, bsum, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(KT), 0, st, counts, nscan, bsum, starts);
+    hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(KT), 0, st, p2, n2, cell_of, starts, fill, sorted);
+    hipLaunchKernelGGL(k_grid_query, dim3((unsigned)((n1 + KT - 1) / KT)), dim3(KT), 0, st, p1, n1, gi, starts, sorted, dists, idx, unresolved);
+    hipLaunchKernelGGL(k_knn1_rest, dim3(1024), dim3(KT), 0, st, p1, p2, n2, gi, unresolved, dists, idx);
+    return E2E_OK;
+}
 
 int e2e_knn1_fwd(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists, long long* idx, void* workspace,
-                 void* stream) {
-    E2E_REQUIRE(n1 > 0 && n2 > 0 && n2 < 0xFFFFFFFFll, E2E_ERR_ARG, "e2e_knn1_fwd: bad sizes n1=%lld n2=%lld", (long long)n1, (long long)n2);
+                  int algorithm, void* stream) {
+    E2E_REQUIRE(n1 > 0 && n2 > 0 && n2 < 0xFFFFFFFFll && n1 < 0xFFFFFFFFll, E2E_ERR_ARG, "e2e_knn1_fwd: bad sizes n1=%lld n2=%lld", (long long)n1, (long long)n2);
     E2E_REQUIRE(p1 && p2 && dists && idx && workspace, E2E_ERR_ARG, "e2e_knn1_fwd: null pointer");
+    E2E_REQUIRE(algorithm >= 0 && algorithm <= 2, E2E_ERR_ARG, "e2e_knn1_fwd: algorithm %d (0 auto, 1 brute force, 2 grid)", algorithm);
     hipStream_t st = (hipStream_t)stream;
+    const bool grid = algorithm == 2 || (algorithm == 0 && n2 >= KNN_GRID_MIN_N2);
+    const int rc = grid ? knn1_grid(p1, n1, p2, n2, dists, idx, workspace, st) : knn1_brute(p1, n1, p2, n2, dists, idx, workspace, st);
+    if (rc) return rc;
+    E2E_LAUNCH_CHECK("e2e_knn1_fwd");
+    return E2E_OK;
+}
+
+static int knn1_brute(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists, long long* idx, void* workspace, hipStream_t st) {
     unsigned long long* best = (unsigned long long*)workspace;
     const int qblocks = (int)((n1 + KT - 1) / KT);
     // enough (query-block, slice) workgroups for ~8 per CU; slices are whole tiles

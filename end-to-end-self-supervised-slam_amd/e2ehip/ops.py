@@ -323,15 +323,18 @@ def transform_points(points, T):
     return _TransformPoints.apply(points, T)
 
 
+KNN_ALGORITHMS = {"auto": 0, "brute": 1, "grid": 2}
+
+
 class _Knn1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, p1, p2):
+    def forward(ctx, p1, p2, algorithm):
         a, b = L.dev(p1, "p1").contiguous(), L.dev(p2, "p2").contiguous()
         n1, n2 = a.shape[0], b.shape[0]
         d = torch.empty(n1, device=a.device, dtype=torch.float32)
         idx = torch.empty(n1, device=a.device, dtype=torch.int64)
-        ws = torch.empty(L.load().e2e_knn1_workspace_bytes(n1), device=a.device, dtype=torch.uint8)
-        L.call("e2e_knn1_fwd", L.ptr(a), n1, L.ptr(b), n2, L.ptr(d), L.ptr(idx), L.ptr(ws), L.stream())
+        ws = torch.empty(L.load().e2e_knn1_workspace_bytes(n1, n2), device=a.device, dtype=torch.uint8)
+        L.call("e2e_knn1_fwd", L.ptr(a), n1, L.ptr(b), n2, L.ptr(d), L.ptr(idx), L.ptr(ws), algorithm, L.stream())
         ctx.save_for_backward(a, b, idx)
         ctx.mark_non_differentiable(idx)
         return d, idx
@@ -343,11 +346,11 @@ class _Knn1(torch.autograd.Function):
         gd = gd.contiguous()
         gp = torch.empty_like(a)
         L.call("e2e_knn1_bwd", L.ptr(gd), L.ptr(a), L.ptr(b), L.ptr(idx), a.shape[0], L.ptr(gp), L.stream())
-        return gp, None
+        return gp, None, None
 
 
-def knn1(p1, p2):
-    """K=1 nearest neighbour of every row of p1 (P1,3) among p2 (P2,3): (squared dists (P1,), idx (P1,) int64).
+def knn1(p1, p2, algorithm="auto"):
+    """algorithm: "auto" | "brute" | "grid" (identical results).  K=1 nearest neighbour of every row of p1 (P1,3) among p2 (P2,3): (squared dists (P1,), idx (P1,) int64).
     Differentiable wrt p1 (d/dp1 = 2 g (p1 - p2[idx])); p2 is treated as data (the reference detaches it,
     online_adaption.py:643)."""
     for n, t in (("p1", p1), ("p2", p2)):
@@ -357,7 +360,7 @@ def knn1(p1, p2):
         raise NotImplementedError("gradient wrt the reference cloud (p2) is not on the reference path; detach it")
     if p1.shape[0] == 0 or p2.shape[0] == 0:
         raise ValueError("knn1: empty point cloud")
-    return _Knn1.apply(p1, p2)
+    return _Knn1.apply(p1, p2, KNN_ALGORITHMS[algorithm])
 
 
 # ---------------------------------------------------------------------------------------------

@@ -202,10 +202,13 @@ int e2e_pf_fuse_append(float* map_points, float* map_normals, float* map_colors,
 /* ------------------------------------------------------------------------------------------ */
 
 /* p1 (n1,3) queries, p2 (n2,3) references -> dists (n1) squared L2, idx (n1) int64 (first minimum
- * wins).  workspace: e2e_knn1_workspace_bytes(n1) bytes. */
-int64_t e2e_knn1_workspace_bytes(int64_t n1);
+ * wins = smallest index among equal distances).  algorithm: 0 = auto, 1 = brute force (LDS-tiled,
+ * fp32 VALU bound), 2 = exact uniform grid (counting-sort build + shell search with a provable
+ * stopping rule + brute-force finish for the few unbounded queries).  Both give IDENTICAL results.
+ * workspace: e2e_knn1_workspace_bytes(n1, n2) bytes. */
+int64_t e2e_knn1_workspace_bytes(int64_t n1, int64_t n2);
 int e2e_knn1_fwd(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists,
-                 long long* idx, void* workspace, void* stream);
+                 long long* idx, void* workspace, int algorithm, void* stream);
 /* g_p1 = 2 g_dists (p1 - p2[idx]) */
 int e2e_knn1_bwd(const float* g_dists, const float* p1, const float* p2, const long long* idx,
                  int64_t n1, float* g_p1, void* stream);

@@ -153,8 +153,9 @@ def test_pointfusion_edge_cases():
         small.step(c.to(DEV), d.to(DEV), K.to(DEV), _pose().to(DEV))
 
 
+@pytest.mark.parametrize("algo", ["brute", "grid"])
 @pytest.mark.parametrize("n1,n2", [(1, 1), (777, 5000), (4096, 30000), (300, 3)])
-def test_knn1_bitexact(n1, n2):
+def test_knn1_bitexact(n1, n2, algo):
     from e2ehip import ops
     g = torch.Generator().manual_seed(n1 + n2)
     a, b = torch.rand(n1, 3, generator=g), torch.rand(n2, 3, generator=g)
@@ -163,7 +164,7 @@ def test_knn1_bitexact(n1, n2):
         a[0] = b[17]
     d_ref, i_ref = oknn.knn1(a, b)
     ag = a.to(DEV).requires_grad_(True)
-    d, i = ops.knn1(ag, b.to(DEV))
+    d, i = ops.knn1(ag, b.to(DEV), algo)
     assert torch.equal(d.detach().cpu(), d_ref) and torch.equal(i.cpu(), i_ref)
     w = torch.rand(n1, generator=g)
     (d * w.to(DEV)).sum().backward()
@@ -191,3 +192,30 @@ def test_knn_full_frame_properties():
     # (d) a subset agrees with the CPU oracle exactly
     dr, ir = oknn.knn1(q[:2000].cpu(), ref.cpu())
     assert torch.equal(d[:2000].cpu(), dr) and torch.equal(i[:2000].cpu(), ir)
+
+
+@pytest.mark.parametrize("case", ["surface", "clustered", "far_queries", "degenerate"])
+def test_knn_grid_equals_brute(case):
+    """The grid search must return exactly what the brute force returns (distances AND indices, ties included) on
+    surface-like data, heavy clusters with duplicates, queries far outside the reference set, and a degenerate cloud."""
+    from e2ehip import ops
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    if case == "surface":          # two overlapping depth-map-like sheets, queries slightly off the surface
+        u = torch.rand(120000, 2, generator=g) * 4 - 2
+        ref = torch.stack([u[:, 0], u[:, 1], 2.2 + 0.3 * torch.sin(u[:, 0] * 2) + 0.002 * torch.randn(120000, generator=g)], 1)
+        v = torch.rand(60000, 2, generator=g) * 4.4 - 2.2
+        q = torch.stack([v[:, 0] + 0.06, v[:, 1], 2.2 + 0.3 * torch.sin(v[:, 0] * 2)], 1)
+    elif case == "clustered":
+        c = torch.randn(50, 3, generator=g)
+        ref = (c[torch.randint(0, 50, (60000,), generator=g)] + 0.01 * torch.randn(60000, 3, generator=g))
+        ref[1000:1400] = ref[7]                                  # 400 exact duplicates
+        q = torch.cat([ref[torch.randint(0, 60000, (5000,), generator=g)], torch.randn(20000, 3, generator=g)], 0)
+    elif case == "far_queries":
+        ref = torch.rand(20000, 3, generator=g)
+        q = torch.cat([torch.rand(3000, 3, generator=g) * 40 - 20, torch.rand(3000, 3, generator=g)], 0)
+    else:
+        ref = torch.zeros(9000, 3) + 1.5                          # zero extent
+        q = torch.rand(2000, 3, generator=g)
+    db, ib = ops.knn1(q.to(DEV), ref.to(DEV), "brute")
+    dg, ig = ops.knn1(q.to(DEV), ref.to(DEV), "grid")
+    assert torch.equal(db, dg) and torch.equal(ib, ig)
