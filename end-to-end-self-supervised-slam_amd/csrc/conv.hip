@@ -1,0 +1,584 @@
+// conv.hip -- the depth network's convolutions for gfx950: fp32 implicit GEMM on v_mfma_f32_32x32x2_f32
+// (exact fp32: a k-ordered fmaf chain, so the 1e-4 parity tolerance holds; bf16 MFMA would not).
+// Replaces torch/MIOpen conv + separate BN / activation / reflection-pad / upsample / concat kernels of
+// depth_estimation/networks.py:44-57 (encoder), :157-189 (ConvBlock / Conv3x3), :277-292 (decoder).
+//
+// Activations are NHWC.  One GEMM kernel serves
+//   forward        out[n, co]  = act( scale[co] * sum_k A[n,k] W[k,co] + shift[co] (+ res[n,co]) )
+//                  n = (b,oh,ow), k = (kh,kw,ci), A gathered on the fly: stride, zero / reflection padding, nearest x2
+//                  upsample of a low-res source and channel concatenation with a skip tensor -- none materialised;
+//   backward-data  dXp[n, ci] = sum_k A'[n,k] W'[k,ci],  n = (b,y,x) over the (padded) input domain, k = (kh,kw,co),
+//                  A'[n,k] = dZ[b,(y-kh)/s,(x-kw)/s,co] where that is an integer in range  (TRANSPOSED gather)
+// and a second kernel computes backward-weight as a split-K GEMM over pixels with fixed-order slab reduction.
+//
+// Tiling: workgroup = WM x WN waves, each wave owns 32 rows x (32*TN) columns (TN accumulators of 16 VGPRs);
+// K is consumed in chunks of 16 through double-buffered LDS tiles stored k-major so that both MFMA operands are
+// bank-conflict-free ds_read_b32 (lane l reads [k = 2kk + (l>>5)][i = l & 31]).  fp32 MFMA issues one instruction per
+// 64 cycles per SIMD, so one wave per SIMD with its accumulators in flight saturates the matrix pipe; global loads of
+// the next chunk are issued before the current chunk's MFMAs.
+#include "e2e_common.h"
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+#define CBK 16
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_DISP = 3 };
+
+struct ConvArgs {
+    // sources: channels [0,C1) come from src0 (at 1/up resolution), channels [C1,Cin) from src1 (full resolution)
+    const float* src0;
+    const float* src1;
+    const float* w;        // GEMM B operand, [K][ldw] row-major (k-major), ldw >= Ncols
+    const float* scale;    // per output column or NULL
+    const float* shift;    // per output column or NULL
+    const float* res;      // residual [n][Ncols] or NULL
+    float* out;            // [n][Ncols]
+    int B, Hs, Ws;         // spatial size of the gather SOURCE domain at full resolution (src1 / upsampled src0)
+    int Cin, C1, up;       // gather channels, split point, upsample factor of src0 (1 or 2)
+    int Hd, Wd;            // spatial size of the OUTPUT domain (rows n = (b, yd, xd))
+    int Ncols, ldw;        // GEMM N (= Cout fwd, = Cin of the conv for backward-data) and weight leading dimension
+    int KH, KW, stride, pad, pad_mode;   // pad_mode 0 zeros, 1 reflect (forward only)
+    int off;               // backward-data: offset added to (yd,xd) to get padded-domain coordinates
+    int act;
+    float in_sub, in_mul;  // VEC==1 path only: gathered value -> (v - in_sub) * in_mul  (input normalisation, networks.py:50)
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
+    if (act == ACT_DISP) return 10.f / (1.f + expf(-v)) + 0.01f;          // networks.py:290
+    return v;
+}
+
+// source pixel for output-domain pixel (yd,xd) and tap (kh,kw); returns false when the tap reads a structural zero
+template <bool TRANSPOSED>
+__device__ __forceinline__ bool tap_coord(const ConvArgs& a, int yd, int xd, int kh, int kw, int& ys, int& xs) {
+    if (!TRANSPOSED) {
+        ys = yd * a.stride + kh - a.pad;
+        xs = xd * a.stride + kw - a.pad;
+        if (a.pad_mode == 1) {
+            ys = reflect1(ys, a.Hs);
+            xs = reflect1(xs, a.Ws);
+            return true;
+        }
+        return ys >= 0 && ys < a.Hs && xs >= 0 && xs < a.Ws;
+    } else {
+        const int ty = yd + a.off - kh, tx = xd + a.off - kw;
+        if (ty < 0 || tx < 0) return false;
+        if (a.stride == 2) {
+            if ((ty | tx) & 1) return false;
+            ys = ty >> 1;
+            xs = tx >> 1;
+        } else {
+            ys = ty;
+            xs = tx;
+        }
+        return ys < a.Hs && xs < a.Ws;
+    }
+}
+
+template <int WM, int WN, int TN, int VEC, bool TRANSPOSED>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
+    constexpr int BM = 32 * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
+    constexpr int KQ = CBK / VEC;                          // k-groups (of VEC) per chunk
+    constexpr int A_PER = (KQ + NT / BM - 1) / (NT / BM);  // vector loads of A per thread per chunk (guarded)
+    constexpr int B_CNT = CBK * (BN / 4);                  // float4 loads of the B tile
+    constexpr int B_PER = (B_CNT + NT - 1) / NT;
+    static_assert(NT % BM == 0, "tile / thread-count mismatch");
+    __shared__ float As[2][CBK][BM];
+    __shared__ float Bs[2][CBK][BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int64_t Ntot = (int64_t)a.B * a.Hd * a.Wd;
+    const int64_t n0 = (int64_t)blockIdx.x * BM;
+    const int c0 = blockIdx.y * BN;
+    const int K = a.KH * a.KW * a.Cin;
+    const int nchunks = (K + CBK - 1) / CBK;
+
+    // ---- per-thread A row (fixed for the whole K loop) --------------------------------------------------------------
+    const int arow = tid % BM;
+    const int64_t an = n0 + arow;
+    const bool arow_ok = an < Ntot;
+    int ab = 0, ayd = 0, axd = 0;
+    if (arow_ok) {
+        ab = (int)(an / ((int64_t)a.Hd * a.Wd));
+        const int r = (int)(an - (int64_t)ab * a.Hd * a.Wd);
+        ayd = r / a.Wd;
+        axd = r - ayd * a.Wd;
+    }
+    const int akq0 = tid / BM;                              // this thread's first k-quad inside a chunk
+    const int Hl = a.Hs / a.up, Wl = a.Ws / a.up, C2 = a.Cin - a.C1;
+
+    f4v areg[A_PER];
+    float areg1[A_PER];
+    f4v breg[B_PER];
+
+    auto load_chunk = [&](int chunk) {
+        const int kbase = chunk * CBK;
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            const int kq = akq0 + j * (NT / BM);
+            if (VEC == 4) {
+                const int k = kbase + kq * 4;                // Cin % 16 == 0: the quad never straddles a tap or the concat split
+                f4v v = (f4v){0.f, 0.f, 0.f, 0.f};
+                if (arow_ok && kq < KQ && k < K) {
+                    const int tap = k / a.Cin, ci = k - tap * a.Cin;
+                    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+                    int ys, xs;
+                    if (tap_coord<TRANSPOSED>(a, ayd, axd, kh, kw, ys, xs)) {
+                        const float* p = (ci < a.C1)
+                            ? a.src0 + (((int64_t)ab * Hl + ys / a.up) * Wl + xs / a.up) * a.C1 + ci
+                            : a.src1 + (((int64_t)ab * a.Hs + ys) * a.Ws + xs) * C2 + (ci - a.C1);
+                        v = *(const f4v*)p;
+                    }
+                }
+                areg[j] = v;
+            } else {
+                const int k = kbase + kq;
+                float v = 0.f;
+                if (arow_ok && kq < KQ && k < K) {
+                    const int tap = k / a.Cin, ci = k - tap * a.Cin;
+                    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+                    int ys, xs;
+                    if (tap_coord<TRANSPOSED>(a, ayd, axd, kh, kw, ys, xs))
+                        v = (a.src0[(((int64_t)ab * a.Hs + ys) * a.Ws + xs) * a.Cin + ci] - a.in_sub) * a.in_mul;
+                }
+                areg1[j] = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int idx = tid + j * NT;                   // over CBK x (BN/4)
+            const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
+            const int k = kbase + kr, col = c0 + cq * 4;
+            f4v v = (f4v){0.f, 0.f, 0.f, 0.f};
+            if (idx < B_CNT && k < K && col < a.ldw) v = *(const f4v*)(a.w + (int64_t)k * a.ldw + col);   // ldw % 4 == 0, zero-padded columns
+            breg[j] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            const int kq = akq0 + j * (NT / BM);
+            if (kq >= KQ) continue;
+            if (VEC == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[buf][kq * 4 + e][arow] = areg[j][e];
+            } else {
+                As[buf][kq][arow] = areg1[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int idx = tid + j * NT;
+            if (idx >= B_CNT) continue;
+            const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
+            *(f4v*)&Bs[buf][kr][cq * 4] = breg[j];
+        }
+    };
+
+    f16v acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    const int arow_l = wm * 32 + (lane & 31), khalf = lane >> 5;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk(c + 1);             // global loads in flight under the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < CBK / 2; ++kk) {
+            const float av = As[buf][kk * 2 + khalf][arow_l];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const float bv = Bs[buf][kk * 2 + khalf][(wn * TN + t) * 32 + (lane & 31)];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5) ----------------------------
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int col = c0 + (wn * TN + t) * 32 + (lane & 31);
+        if (col >= a.Ncols) continue;
+        const float sc = a.scale ? a.scale[col] : 1.f, sh = a.shift ? a.shift[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t n = n0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (n >= Ntot) continue;
+            float v = fmaf(acc[t][r], sc, sh);
+            if (a.res) v += a.res[n * a.Ncols + col];
+            a.out[n * a.Ncols + col] = apply_act(v, a.act);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward-weight: dW[m, n] = sum_p dZ[p, m] * X[p, n]   (m = cout, n = (kh,kw,ci) [+ 1 ones-column for the bias],
+// p = output pixel) as a split-K GEMM: grid.z slices of the pixel range write partial slabs, k_wgrad_reduce adds
+// them in slice order (deterministic) and scatters to torch's (Cout,Cin,KH,KW) layout.
+// ---------------------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* dz;       // [P][Cout]
+    const float* src0;
+    const float* src1;
+    float* slabs;          // [S][Mpad][Npad]
+    int B, Hs, Ws, Cin, C1, up;
+    int Ho, Wo, Cout;
+    int KH, KW, stride, pad, pad_mode;
+    int Ngemm;             // KH*KW*Cin (+1 when has_bias)
+    int has_bias;
+    int Mpad, Npad;
+    int64_t pix_per_slice;
+    float in_sub, in_mul;
+    int vec;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_wgrad_gemm(WgradArgs a) {
+    constexpr int BM = 64, BN = 64, NT = 256;              // 2x2 waves of 32x32
+    __shared__ float As[2][CBK][BM];
+    __shared__ float Bs[2][CBK][BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int m0 = blockIdx.y * BM, nn0 = blockIdx.x * BN;
+    const int64_t P = (int64_t)a.B * a.Ho * a.Wo;
+    const int64_t p0 = (int64_t)blockIdx.z * a.pix_per_slice;
+    const int64_t p1 = (p0 + a.pix_per_slice < P) ? p0 + a.pix_per_slice : P;
+    const int nchunks = (int)((p1 - p0 + CBK - 1) / CBK);
+    const int Hl = a.Hs / a.up, Wl = a.Ws / a.up, C2 = a.Cin - a.C1;
+    const int Kconv = a.KH * a.KW * a.Cin;
+
+    // A tile: CBK pixels x 64 couts = 256 float4 -> one per thread.  B tile: CBK pixels x 64 n-columns.
+    const int a_kr = tid / (BM / 4), a_mq = tid % (BM / 4);
+    const int b_kr = tid / (BN / 4), b_nq = tid % (BN / 4);
+    // this thread's B column quad is fixed over the K loop: decode (tap, ci) once
+    const int ncol = nn0 + b_nq * 4;
+    int tap = 0, ci = 0, kh = 0, kw = 0;
+    const bool col_conv = ncol < Kconv;
+    if (col_conv && VEC == 4) { tap = ncol / a.Cin; ci = ncol - tap * a.Cin; kh = tap / a.KW; kw = tap - kh * a.KW; }
+
+    f4v areg, breg;
+    auto load_chunk = [&](int chunk) {
+        {
+            const int64_t p = p0 + (int64_t)chunk * CBK + a_kr;
+            const int m = m0 + a_mq * 4;
+            f4v v = (f4v){0.f, 0.f, 0.f, 0.f};
+            if (p < p1 && m < a.Cout) {
+                if (a.Cout % 4 == 0) v = *(const f4v*)(a.dz + p * a.Cout + m);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (m + e < a.Cout) v[e] = a.dz[p * a.Cout + m + e];
+            }
+            areg = v;
+        }
+        {
+            const int64_t p = p0 + (int64_t)chunk * CBK + b_kr;
+            f4v v = (f4v){0.f, 0.f, 0.f, 0.f};
+            if (p < p1) {
+                const int b = (int)(p / ((int64_t)a.Ho * a.Wo));
+                const int r = (int)(p - (int64_t)b * a.Ho * a.Wo);
+                const int oh = r / a.Wo, ow = r - oh * a.Wo;
+                if (VEC == 4) {
+                    if (col_conv) {
+                        int ys = oh * a.stride + kh - a.pad, xs = ow * a.stride + kw - a.pad;
+                        bool ok = true;
+                        if (a.pad_mode == 1) { ys = reflect1(ys, a.Hs); xs = reflect1(xs, a.Ws); }
+                        else ok = ys >= 0 && ys < a.Hs && xs >= 0 && xs < a.Ws;
+                        if (ok) {
+                            const float* q = (ci < a.C1)
+                                ? a.src0 + (((int64_t)b * Hl + ys / a.up) * Wl + xs / a.up) * a.C1 + ci
+                                : a.src1 + (((int64_t)b * a.Hs + ys) * a.Ws + xs) * C2 + (ci - a.C1);
+                            v = *(const f4v*)q;
+                        }
+                    } else if (a.has_bias && ncol == Kconv) {
+                        v[0] = 1.f;                            // ones column: dW[:, Kconv] = sum_p dZ = bias gradient
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = ncol + e;
+                        if (n < Kconv) {
+                            const int tp = n / a.Cin, c = n - tp * a.Cin, kh1 = tp / a.KW, kw1 = tp - kh1 * a.KW;
+                            const int ys = oh * a.stride + kh1 - a.pad, xs = ow * a.stride + kw1 - a.pad;
+                            if (ys >= 0 && ys < a.Hs && xs >= 0 && xs < a.Ws)
+                                v[e] = (a.src0[(((int64_t)b * a.Hs + ys) * a.Ws + xs) * a.Cin + c] - a.in_sub) * a.in_mul;
+                        } else if (a.has_bias && n == Kconv) v[e] = 1.f;
+                    }
+                }
+            }
+            breg = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        *(f4v*)&As[buf][a_kr][a_mq * 4] = areg;
+        *(f4v*)&Bs[buf][b_kr][b_nq * 4] = breg;
+    };
+    f16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    const int khalf = lane >> 5;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < CBK / 2; ++kk) {
+            const float av = As[buf][kk * 2 + khalf][wm * 32 + (lane & 31)];
+            const float bv = Bs[buf][kk * 2 + khalf][wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    float* slab = a.slabs + (int64_t)blockIdx.z * a.Mpad * a.Npad;
+    const int n = nn0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (m < a.Mpad && n < a.Npad) slab[(int64_t)m * a.Npad + n] = acc[r];
+    }
+}
+
+// sum the slabs in slice order; scatter to dW (Cout,Cin,KH,KW) [accumulating when beta = 1] and the bias gradient
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, int S, int Mpad, int Npad, int Cout, int Cin,
+                                                      int KH, int KW, int has_bias, float* __restrict__ dw, float* __restrict__ dbias,
+                                                      int accumulate) {
+    const int Kconv = KH * KW * Cin;
+    const int64_t total = (int64_t)Cout * (Kconv + (has_bias ? 1 : 0));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / (Kconv + (has_bias ? 1 : 0))), n = (int)(i - (int64_t)m * (Kconv + (has_bias ? 1 : 0)));
+        float s = 0.f;
+        for (int z = 0; z < S; ++z) s += slabs[((int64_t)z * Mpad + m) * Npad + n];
+        if (n < Kconv) {
+            const int tap = n / Cin, ci = n - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
+            float* d = dw + (((int64_t)m * Cin + ci) * KH + kh) * KW + kw;
+            *d = accumulate ? *d + s : s;
+        } else if (dbias) {
+            dbias[m] = accumulate ? dbias[m] + s : s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// helpers: weight layout transforms, activation backward, reflection-pad / upsample / concat adjoint
+// ---------------------------------------------------------------------------------------------------------------------
+// W (Cout,Cin,KH,KW) -> Wf [(kh,kw,ci)][ldf] (forward B operand) and Wb [(kh,kw,co)][ldb] (backward-data B operand)
+__global__ __launch_bounds__(256) void k_weight_layouts(const float* __restrict__ w, int Cout, int Cin, int KH, int KW,
+                                                        float* __restrict__ wf, int ldf, float* __restrict__ wb, int ldb) {
+    const int64_t total = (int64_t)Cout * Cin * KH * KW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t t = i;
+        const int kw = (int)(t % KW); t /= KW;
+        const int kh = (int)(t % KH); t /= KH;
+        const int ci = (int)(t % Cin); t /= Cin;
+        const int co = (int)t;
+        const float v = w[i];
+        if (wf) wf[((int64_t)(kh * KW + kw) * Cin + ci) * ldf + co] = v;
+        if (wb) wb[((int64_t)(kh * KW + kw) * Cout + co) * ldb + ci] = v;
+    }
+}
+
+// dZ = dY * act'(Y) * scale[c]     (Y = the activation's OUTPUT; ELU' = y+1 for y<=0; DISP' = (y-.01)(1-(y-.01)/10))
+__global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ scale,
+                                                 float* __restrict__ dz, int64_t n, int C, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float g = dy[i];
+        const float v = y[i];
+        if (act == ACT_RELU) g = v > 0.f ? g : 0.f;
+        else if (act == ACT_ELU) g = v > 0.f ? g : g * (v + 1.f);
+        else if (act == ACT_DISP) { const float s = (v - 0.01f) * 0.1f; g = g * 10.f * s * (1.f - s); }
+        if (scale) g *= scale[i % C];
+        dz[i] = g;
+    }
+}
+
+// Adjoint of the forward gather of one convolution input: dXp (B,Hp,Wp,Cin) over the padded full-resolution domain
+// (Hp = Hs + 2*pp with pp = 1 for reflection padding, 0 otherwise) -> d src0 (B,Hs/up,Ws/up,C1) [+ d src1 (B,Hs,Ws,C2)].
+// Every destination element GATHERS its contributors in a fixed order (no atomics): the reflect-pad copies of a pixel
+// and, for src0, the up x up block of full-resolution pixels that read it.
+__global__ __launch_bounds__(256) void k_gather_adjoint(const float* __restrict__ dxp, int B, int Hs, int Ws, int Cin, int C1, int up,
+                                                        int pp, float* __restrict__ d0, float* __restrict__ d1, int acc0, int acc1) {
+    const int Hp = Hs + 2 * pp, Wp = Ws + 2 * pp, C2 = Cin - C1, Hl = Hs / up, Wl = Ws / up;
+    const int64_t n0 = (int64_t)B * Hl * Wl * C1, n1 = (int64_t)B * Hs * Ws * C2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n0 + n1; i += (int64_t)gridDim.x * 256) {
+        const bool first = i < n0;
+        int64_t t = first ? i : i - n0;
+        const int Cx = first ? C1 : C2, Hx = first ? Hl : Hs, Wx = first ? Wl : Ws, u = first ? up : 1;
+        const int c = (int)(t % Cx); t /= Cx;
+        const int x = (int)(t % Wx); t /= Wx;
+        const int y = (int)(t % Hx); t /= Hx;
+        const int b = (int)t;
+        const int cc = first ? c : C1 + c;
+        float s = 0.f;
+        for (int dy = 0; dy < u; ++dy)
+            for (int dx = 0; dx < u; ++dx) {
+                const int fy = y * u + dy, fx = x * u + dx;                 // full-resolution pixel
+                // padded positions that map to (fy,fx): itself (+pp) and its reflections across the borders
+                int ys[3] = {fy + pp, -1, -1}, xs[3] = {fx + pp, -1, -1};
+                if (pp) {
+                    if (fy == 1) ys[1] = 0;
+                    if (fy == Hs - 2) ys[2] = Hp - 1;
+                    if (fx == 1) xs[1] = 0;
+                    if (fx == Ws - 2) xs[2] = Wp - 1;
+                }
+                for (int iy = 0; iy < 3; ++iy)
+                    for (int ix = 0; ix < 3; ++ix)
+                        if (ys[iy] >= 0 && xs[ix] >= 0) s += dxp[(((int64_t)b * Hp + ys[iy]) * Wp + xs[ix]) * Cin + cc];
+            }
+        float* d = first ? d0 + i : d1 + (i - n0);
+        const int acc = first ? acc0 : acc1;
+        *d = acc ? *d + s : s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------------
+static inline int egrid(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+template <bool TR>
+static void launch_gemm(const ConvArgs& a, int vec, hipStream_t st) {
+    const int64_t Ntot = (int64_t)a.B * a.Hd * a.Wd;
+    if (vec == 1) {
+        dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 63) / 64));
+        hipLaunchKernelGGL((k_conv_gemm<4, 1, 2, 1, TR>), g, dim3(256), 0, st, a);
+        return;
+    }
+    // tile choice: enough workgroups for 256 CUs.  128x64 for large pixel counts, 64x64 for medium, 32x128 for the deep, small-spatial layers
+    const int64_t wg_big = ((Ntot + 127) / 128) * ((a.Ncols + 63) / 64);
+    if (a.Ncols <= 32) {
+        dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 31) / 32));
+        hipLaunchKernelGGL((k_conv_gemm<4, 1, 1, 4, TR>), g, dim3(256), 0, st, a);
+    } else if (wg_big >= 512) {
+        dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 63) / 64));
+        hipLaunchKernelGGL((k_conv_gemm<4, 1, 2, 4, TR>), g, dim3(256), 0, st, a);
+    } else if (((Ntot + 63) / 64) * ((a.Ncols + 63) / 64) >= 256 || a.Ncols < 128) {
+        dim3 g((unsigned)((Ntot + 63) / 64), (unsigned)((a.Ncols + 63) / 64));
+        hipLaunchKernelGGL((k_conv_gemm<2, 2, 1, 4, TR>), g, dim3(256), 0, st, a);
+    } else {
+        dim3 g((unsigned)((Ntot + 31) / 32), (unsigned)((a.Ncols + 127) / 128));
+        hipLaunchKernelGGL((k_conv_gemm<1, 4, 1, 4, TR>), g, dim3(256), 0, st, a);
+    }
+}
+
+extern "C" {
+
+int e2e_conv_weight_layouts(const float* w, int Cout, int Cin, int KH, int KW, float* w_fwd, int ld_fwd, float* w_bwd,
+                            int ld_bwd, void* stream) {
+    E2E_REQUIRE(w && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && (w_fwd || w_bwd), E2E_ERR_ARG, "e2e_conv_weight_layouts: bad argument");
+    E2E_REQUIRE((!w_fwd || (ld_fwd >= Cout && ld_fwd % 4 == 0)) && (!w_bwd || (ld_bwd >= Cin && ld_bwd % 4 == 0)), E2E_ERR_ARG,
+                "e2e_conv_weight_layouts: leading dimensions must cover the columns and be multiples of 4");
+    hipLaunchKernelGGL(k_weight_layouts, dim3(egrid((int64_t)Cout * Cin * KH * KW)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, KH,
+                       KW, w_fwd, ld_fwd, w_bwd, ld_bwd);
+    E2E_LAUNCH_CHECK("e2e_conv_weight_layouts");
+    return E2E_OK;
+}
+
+int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const float* w_fwd, int ld_fwd, const float* scale,
+                   const float* shift, const float* residual, float* out, int B, int Hs, int Ws, int Cin, int Cout, int KH,
+                   int KW, int stride, int pad, int pad_mode, int act, float in_sub, float in_mul, void* stream) {
+    E2E_REQUIRE(src0 && w_fwd && out && B > 0 && Hs > 0 && Ws > 0 && Cin > 0 && Cout > 0, E2E_ERR_ARG, "e2e_conv2d_fwd: bad argument");
+    E2E_REQUIRE(up == 1 || up == 2, E2E_ERR_ARG, "e2e_conv2d_fwd: upsample factor must be 1 or 2");
+    E2E_REQUIRE(C1 > 0 && C1 <= Cin && (C1 == Cin || src1), E2E_ERR_ARG, "e2e_conv2d_fwd: bad channel split");
+    E2E_REQUIRE(pad_mode == 0 || (pad_mode == 1 && pad == 1 && Hs >= 2 && Ws >= 2), E2E_ERR_ARG, "e2e_conv2d_fwd: reflection padding needs pad == 1");
+    E2E_REQUIRE(stride == 1 || stride == 2, E2E_ERR_ARG, "e2e_conv2d_fwd: stride must be 1 or 2");
+    E2E_REQUIRE(Hs % up == 0 && Ws % up == 0 && ld_fwd % 4 == 0 && ld_fwd >= Cout, E2E_ERR_ARG, "e2e_conv2d_fwd: bad sizes");
+    const int vec = (Cin % 16 == 0 && C1 % 4 == 0 && (Cin - C1) % 4 == 0) ? 4 : 1;
+    E2E_REQUIRE(vec == 4 || (C1 == Cin && up == 1), E2E_ERR_ARG, "e2e_conv2d_fwd: the scalar path (Cin %% 16 != 0) takes a single full-resolution source");
+    ConvArgs a{};
+    a.src0 = src0; a.src1 = src1; a.w = w_fwd; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
+    a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cin = Cin; a.C1 = C1; a.up = up;
+    a.Hd = (Hs + 2 * pad - KH) / stride + 1; a.Wd = (Ws + 2 * pad - KW) / stride + 1;
+    a.Ncols = Cout; a.ldw = ld_fwd; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_mode = pad_mode; a.off = 0; a.act = act;
+    a.in_sub = in_sub; a.in_mul = in_mul;
+    launch_gemm<false>(a, vec, (hipStream_t)stream);
+    E2E_LAUNCH_CHECK("e2e_conv2d_fwd");
+    return E2E_OK;
+}
+
+int e2e_conv2d_bwd_data(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout,
+                        int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, void* stream) {
+    E2E_REQUIRE(dz && w_bwd && dxp && B > 0 && Cin > 0 && Cout > 0 && Cout % 16 == 0, E2E_ERR_ARG, "e2e_conv2d_bwd_data: bad argument (Cout %% 16 == 0)");
+    E2E_REQUIRE(ld_bwd % 4 == 0 && ld_bwd >= Cin && (stride == 1 || stride == 2), E2E_ERR_ARG, "e2e_conv2d_bwd_data: bad sizes");
+    ConvArgs a{};
+    a.src0 = dz; a.src1 = nullptr; a.w = w_bwd; a.out = dxp;
+    a.B = B; a.Hs = Ho; a.Ws = Wo; a.Cin = Cout; a.C1 = Cout; a.up = 1;
+    const int pp = pad_mode == 1 ? pad : 0;                // reflect: produce the whole padded domain, folded afterwards
+    a.Hd = Hs + 2 * pp; a.Wd = Ws + 2 * pp; a.off = pad_mode == 1 ? 0 : pad;
+    a.Ncols = Cin; a.ldw = ld_bwd; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_mode = 0; a.act = ACT_NONE;
+    launch_gemm<true>(a, 4, (hipStream_t)stream);
+    E2E_LAUNCH_CHECK("e2e_conv2d_bwd_data");
+    return E2E_OK;
+}
+
+int e2e_conv2d_gather_adjoint(const float* dxp, int B, int Hs, int Ws, int Cin, int C1, int up, int padded, float* d_src0,
+                              float* d_src1, int accumulate0, int accumulate1, void* stream) {
+    E2E_REQUIRE(dxp && d_src0 && B > 0 && Cin > 0 && C1 > 0 && C1 <= Cin && (C1 == Cin || d_src1) && (up == 1 || up == 2), E2E_ERR_ARG,
+                "e2e_conv2d_gather_adjoint: bad argument");
+    const int64_t n = (int64_t)B * (Hs / up) * (Ws / up) * C1 + (int64_t)B * Hs * Ws * (Cin - C1);
+    hipLaunchKernelGGL(k_gather_adjoint, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, dxp, B, Hs, Ws, Cin, C1, up, padded ? 1 : 0,
+                       d_src0, d_src1, accumulate0, accumulate1);
+    E2E_LAUNCH_CHECK("e2e_conv2d_gather_adjoint");
+    return E2E_OK;
+}
+
+int e2e_conv2d_act_bwd(const float* dy, const float* y, const float* scale, float* dz, int64_t n, int C, int act, void* stream) {
+    E2E_REQUIRE(dy && y && dz && n > 0 && C > 0 && act >= 0 && act <= 3, E2E_ERR_ARG, "e2e_conv2d_act_bwd: bad argument");
+    hipLaunchKernelGGL(k_act_bwd, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, scale, dz, n, C, act);
+    E2E_LAUNCH_CHECK("e2e_conv2d_act_bwd");
+    return E2E_OK;
+}
+
+int64_t e2e_conv2d_wgrad_workspace_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int has_bias) {
+    const int Ng = KH * KW * Cin + (has_bias ? 1 : 0);
+    const int Mpad = (Cout + 63) / 64 * 64, Npad = (Ng + 63) / 64 * 64;
+    const int64_t P = (int64_t)B * Ho * Wo;
+    const int64_t tiles = (int64_t)(Mpad / 64) * (Npad / 64);
+    int64_t S = (1024 + tiles - 1) / tiles;                 // ~4 workgroups per CU in total
+    const int64_t maxS = (P + 255) / 256;                   // at least 256 pixels per slice
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    return S * Mpad * Npad;
+}
+
+int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1, int C1, int up, float* dw, float* dbias,
+                          float* workspace, int B, int Hs, int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride,
+                          int pad, int pad_mode, int accumulate, float in_sub, float in_mul, void* stream) {
+    E2E_REQUIRE(dz && src0 && dw && workspace && B > 0 && Cin > 0 && Cout > 0, E2E_ERR_ARG, "e2e_conv2d_bwd_weight: bad argument");
+    const int vec = (Cin % 4 == 0 && C1 % 4 == 0) ? 4 : 1;
+    E2E_REQUIRE(vec == 4 || (C1 == Cin && up == 1 && pad_mode == 0), E2E_ERR_ARG, "e2e_conv2d_bwd_weight: scalar path takes one full-resolution zero-padded source");
+    WgradArgs a{};
+    a.dz = dz; a.src0 = src0; a.src1 = src1; a.slabs = workspace;
+    a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cin = Cin; a.C1 = C1; a.up = up; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+    a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_mode = pad_mode; a.has_bias = dbias ? 1 : 0;
+    a.Ngemm = KH * KW * Cin + a.has_bias;
+    a.Mpad = (Cout + 63) / 64 * 64; a.Npad = (a.Ngemm + 63) / 64 * 64;
+    a.in_sub = in_sub; a.in_mul = in_mul; a.vec = vec;
+    const int64_t P = (int64_t)B * Ho * Wo;
+    const int64_t S = e2e_conv2d_wgrad_workspace_floats(B, Ho, Wo, Cin, Cout, KH, KW, a.has_bias) / ((int64_t)a.Mpad * a.Npad);
+    a.pix_per_slice = ((P + S - 1) / S + CBK - 1) / CBK * CBK;
+    const int Sz = (int)((P + a.pix_per_slice - 1) / a.pix_per_slice);
+    dim3 g((unsigned)(a.Npad / 64), (unsigned)(a.Mpad / 64), (unsigned)Sz);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec == 4) hipLaunchKernelGGL(k_wgrad_gemm<4>, g, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_wgrad_gemm<1>, g, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(egrid((int64_t)Cout * a.Ngemm)), dim3(256), 0, st, workspace, Sz, a.Mpad, a.Npad, Cout, Cin, KH,
+                       KW, a.has_bias, dw, dbias, accumulate);
+    E2E_LAUNCH_CHECK("e2e_conv2d_bwd_weight");
+    return E2E_OK;
+}
+
+}  // extern "C"

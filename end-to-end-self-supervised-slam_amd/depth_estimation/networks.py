@@ -27,11 +27,18 @@ class _ConvBN(nn.Module):
     torch's batch-statistics path (the refinement path always runs BN in eval mode: online_adaption.py:175-184)."""
 
     @staticmethod
-    def run(conv, bn, x, relu):
-        if bn.training:
-            y = bn(nn_ops.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0]))
+    def run(conv, bn, x, relu, residual=None, in_norm=None):
+        """relu?( BN(conv(x)) + residual? ).  BN is folded into the convolution's epilogue when it is a constant
+        (eval mode AND frozen parameters: the refinement mode freezes every parameter whose name contains "bn",
+        online_adaption.py:182-184); a BatchNorm that still trains (the `downsample.1` ones) or runs on batch
+        statistics keeps torch's op so that its parameters receive their gradients."""
+        if bn.training or bn.weight.requires_grad or bn.bias.requires_grad:
+            y = bn(nn_ops.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0], in_norm=in_norm))
+            if residual is not None:
+                y = y + residual
             return torch.relu(y) if relu else y
-        return nn_ops.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0], "zeros", "relu" if relu else None, _bn_args(bn))
+        return nn_ops.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0], "zeros", "relu" if relu else None, _bn_args(bn),
+                             residual=residual, in_norm=in_norm)
 
 
 class BasicBlock(nn.Module):
@@ -49,8 +56,7 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         idt = x if self.downsample is None else _ConvBN.run(self.downsample[0], self.downsample[1], x, False)
         out = _ConvBN.run(self.conv1, self.bn1, x, True)
-        out = _ConvBN.run(self.conv2, self.bn2, out, False)
-        return torch.relu(out + idt)
+        return _ConvBN.run(self.conv2, self.bn2, out, True, residual=idt)      # relu(bn2(conv2) + identity), one launch
 
 
 class Bottleneck(nn.Module):
@@ -71,8 +77,7 @@ class Bottleneck(nn.Module):
         idt = x if self.downsample is None else _ConvBN.run(self.downsample[0], self.downsample[1], x, False)
         out = _ConvBN.run(self.conv1, self.bn1, x, True)
         out = _ConvBN.run(self.conv2, self.bn2, out, True)
-        out = _ConvBN.run(self.conv3, self.bn3, out, False)
-        return torch.relu(out + idt)
+        return _ConvBN.run(self.conv3, self.bn3, out, True, residual=idt)
 
 
 class ResNet(nn.Module):
@@ -150,8 +155,8 @@ class ResnetEncoder(nn.Module):
     def forward(self, input_image):
         """(B,H,W,3) channels-last image in [0,1] -> the five feature maps (NCHW shape, NHWC memory)."""
         e = self.encoder
-        x = (input_image.permute(0, 3, 1, 2) - 0.45) / 0.225       # a permuted view of NHWC memory == channels_last
-        x = _ConvBN.run(e.conv1, e.bn1, x, True)
+        # a permuted view of the NHWC frame IS a channels_last tensor; (x - 0.45) / 0.225 happens inside the stem's gather
+        x = _ConvBN.run(e.conv1, e.bn1, input_image.permute(0, 3, 1, 2), True, in_norm=(0.45, 1.0 / 0.225))
         self.features = [x]
         x = nn_ops.max_pool_3x3_s2(x)
         for stage in (e.layer1, e.layer2, e.layer3, e.layer4):
@@ -169,8 +174,8 @@ class Conv3x3(nn.Module):
         self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)     # kept for attribute compatibility
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
 
-    def forward(self, x, act=None):
-        return nn_ops.conv2d(x, self.conv.weight, self.conv.bias, 1, 1, self.pad_mode, act)
+    def forward(self, x, act=None, skip=None, upsample=1):
+        return nn_ops.conv2d(x, self.conv.weight, self.conv.bias, 1, 1, self.pad_mode, act, skip=skip, upsample=upsample)
 
 
 class ConvBlock(nn.Module):
@@ -181,8 +186,8 @@ class ConvBlock(nn.Module):
         self.conv = Conv3x3(in_channels, out_channels)
         self.nonlin = nn.ELU(inplace=True)
 
-    def forward(self, x):
-        return self.conv(x, act="elu")
+    def forward(self, x, skip=None, upsample=1):
+        return self.conv(x, act="elu", skip=skip, upsample=upsample)
 
 
 class Conv1x1(nn.Module):
@@ -232,8 +237,8 @@ class _DecoderBase(nn.Module):
         x = input_features[-1]
         for i in range(4, -1, -1):
             x = self.convs[("upconv", i, 0)](x)
-            x = nn_ops.upsample2_concat(x, input_features[i - 1] if (self.use_skips and i > 0) else None)
-            x = self.convs[("upconv", i, 1)](x)
+            # nearest x2 upsample + skip concatenation are gather arithmetic inside the next convolution
+            x = self.convs[("upconv", i, 1)](x, skip=input_features[i - 1] if (self.use_skips and i > 0) else None, upsample=2)
             yield i, x
 
 
@@ -259,7 +264,7 @@ class Indoor_DepthDecoder(_DecoderBase):
         self.outputs = {}
         for i, x in self._trunk(input_features):
             if i in self.scales and i == 0:
-                self.outputs[("disp", index, i)] = self.alpha * self.sigmoid(self.convs[("dispconv", i)](x)) + self.beta
+                self.outputs[("disp", index, i)] = self.convs[("dispconv", i)](x, act="disp")   # alpha*sigmoid(.)+beta fused
         return self.outputs
 
 

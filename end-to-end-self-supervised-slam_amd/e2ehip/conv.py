@@ -1,5 +1,13 @@
-"""Native convolution kernels (csrc/conv.hip).  `available()` reports whether the library exports them."""
+"""Native convolutions of the depth network (csrc/conv.hip): fp32-MFMA implicit GEMM with the gather
+(stride, zero / reflection padding, nearest x2 upsample + channel concat) and the epilogue (folded eval-BN /
+bias, residual add, ReLU / ELU / disparity head) fused.  Tensors are NCHW-shaped, channels_last in memory."""
+import torch
+from torch.autograd.function import once_differentiable
+
 from . import _lib as L
+
+ACT = {None: 0, "relu": 1, "elu": 2, "disp": 3}
+CL = torch.channels_last
 
 
 def available():
@@ -9,5 +17,112 @@ def available():
         return False
 
 
-def conv2d(*a, **k):
-    raise NotImplementedError("csrc/conv.hip is not built into this library")
+def supports(weight):
+    """Layer shapes the MFMA path covers: Cout a multiple of 16 (the 1-channel disparity head is the exception)."""
+    return weight.shape[0] % 16 == 0
+
+
+def _cl(t):
+    return t if t.is_contiguous(memory_format=CL) else t.contiguous(memory_format=CL)
+
+
+def _ld(n):
+    return (n + 3) // 4 * 4
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src0, src1, weight, bias, scale, shift, residual, up, stride, pad, pad_mode, act, in_norm):
+        Cout, Cin, KH, KW = weight.shape
+        src0 = _cl(L.dev(src0, "input"))
+        B, C1 = src0.shape[0], src0.shape[1]
+        Hs, Ws = src0.shape[2] * up, src0.shape[3] * up
+        if src1 is not None:
+            src1 = _cl(L.dev(src1, "skip"))
+            if tuple(src1.shape) != (B, Cin - C1, Hs, Ws):
+                raise ValueError(f"skip tensor: expected {(B, Cin - C1, Hs, Ws)}, got {tuple(src1.shape)}")
+        elif C1 != Cin:
+            raise ValueError(f"input has {C1} channels, the convolution expects {Cin}")
+        Ho, Wo = (Hs + 2 * pad - KH) // stride + 1, (Ws + 2 * pad - KW) // stride + 1
+        dev = src0.device
+        w = L.dev(weight, "weight").contiguous()
+        need_bwd_w = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        ldf, ldb = _ld(Cout), _ld(Cin)
+        wf = torch.zeros(KH * KW * Cin, ldf, device=dev, dtype=torch.float32) if ldf != Cout else torch.empty(KH * KW * Cin, ldf, device=dev, dtype=torch.float32)
+        wb = None
+        if need_bwd_w:
+            wb = torch.zeros(KH * KW * Cout, ldb, device=dev, dtype=torch.float32) if ldb != Cin else torch.empty(KH * KW * Cout, ldb, device=dev, dtype=torch.float32)
+        L.call("e2e_conv_weight_layouts", L.ptr(w), Cout, Cin, KH, KW, L.ptr(wf), ldf, L.ptr(wb), ldb, L.stream())
+        # epilogue vectors: y = scale * conv + shift ; a plain bias is shift with unit scale
+        sh = shift
+        if bias is not None:
+            sh = bias if shift is None else shift       # BN-folded callers pass shift only
+        if residual is not None:
+            residual = _cl(L.dev(residual, "residual"))
+        out = torch.empty(B, Cout, Ho, Wo, device=dev, dtype=torch.float32, memory_format=CL)
+        isub, imul = in_norm if in_norm is not None else (0.0, 1.0)
+        L.call("e2e_conv2d_fwd", L.ptr(src0), L.ptr(src1), C1, up, L.ptr(wf), ldf, L.ptr(scale), L.ptr(sh), L.ptr(residual), L.ptr(out),
+               B, Hs, Ws, Cin, Cout, KH, KW, stride, pad, pad_mode, act, float(isub), float(imul), L.stream())
+        ctx.save_for_backward(src0, src1, wb, scale, out)
+        ctx.cfg = (B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, act, up, C1, ldb, float(isub), float(imul),
+                   bias is not None, residual is not None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        src0, src1, wb, scale, out = ctx.saved_tensors
+        (B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, act, up, C1, ldb, isub, imul, has_bias, has_res) = ctx.cfg
+        dev = g.device
+        g = _cl(g)
+        st = L.stream()
+        n = g.numel()
+        # dA = dY * act'(Y) (gradient of the residual branch), dZ = dA * scale (gradient of the convolution output)
+        d_res = None
+        if act != 0 or has_res:
+            dA = torch.empty_like(g) if act != 0 else g
+            if act != 0:
+                L.call("e2e_conv2d_act_bwd", L.ptr(g), L.ptr(out), None, L.ptr(dA), n, Cout, act, st)
+            d_res = dA if has_res else None
+        else:
+            dA = g
+        if scale is not None:
+            dZ = torch.empty_like(g)
+            L.call("e2e_conv2d_act_bwd", L.ptr(dA), L.ptr(out), L.ptr(scale), L.ptr(dZ), n, Cout, 0, st)
+        else:
+            dZ = dA
+        needs = ctx.needs_input_grad
+        g0 = g1 = gw = gb = None
+        if needs[0] or needs[1]:
+            pp = pad if pad_mode == 1 else 0
+            direct = pp == 0 and up == 1 and src1 is None
+            dxp = torch.empty(B, Cin, Hs + 2 * pp, Ws + 2 * pp, device=dev, dtype=torch.float32, memory_format=CL)
+            L.call("e2e_conv2d_bwd_data", L.ptr(dZ), L.ptr(wb), ldb, L.ptr(dxp), B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, st)
+            if direct:
+                g0 = dxp
+            else:
+                g0 = torch.empty(B, C1, Hs // up, Ws // up, device=dev, dtype=torch.float32, memory_format=CL)
+                if src1 is not None:
+                    g1 = torch.empty(B, Cin - C1, Hs, Ws, device=dev, dtype=torch.float32, memory_format=CL)
+                L.call("e2e_conv2d_gather_adjoint", L.ptr(dxp), B, Hs, Ws, Cin, C1, up, 1 if pp else 0, L.ptr(g0), L.ptr(g1), 0, 0, st)
+        if needs[2]:
+            gw = torch.empty(Cout, Cin, KH, KW, device=dev, dtype=torch.float32)
+            gb = torch.empty(Cout, device=dev, dtype=torch.float32) if (has_bias and needs[3]) else None
+            ws = torch.empty(L.load().e2e_conv2d_wgrad_workspace_floats(B, Ho, Wo, Cin, Cout, KH, KW, 1 if gb is not None else 0),
+                             device=dev, dtype=torch.float32)
+            L.call("e2e_conv2d_bwd_weight", L.ptr(dZ), L.ptr(src0), L.ptr(src1), C1, up, L.ptr(gw), L.ptr(gb), L.ptr(ws), B, Hs, Ws, Cin,
+                   Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, 0, isub, imul, st)
+        return g0, g1, gw, gb, None, None, d_res, None, None, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, pad_mode="zeros", act=None, bn_scale_shift=None, residual=None,
+           skip=None, upsample=1, in_norm=None):
+    """act( scale * conv(cat(upsample(x, upsample), skip)) + shift (+ residual) ).
+    bn_scale_shift: (scale, shift) per output channel (folded eval-mode BatchNorm; constants, no gradient)."""
+    if pad_mode not in ("zeros", "reflect"):
+        raise ValueError(f"pad_mode {pad_mode}")
+    scale, shift = bn_scale_shift if bn_scale_shift is not None else (None, None)
+    if bias is not None and bn_scale_shift is not None:
+        raise ValueError("a bias together with a folded BatchNorm is not used by the network")
+    return _Conv2d.apply(x, skip, weight, bias, scale, shift, residual, int(upsample), int(stride), int(padding),
+                         1 if pad_mode == "reflect" else 0, ACT[act], in_norm)

@@ -256,6 +256,54 @@ int e2e_depth_metrics(const float* gt, const float* pred, int64_t n, int mask_ze
 int e2e_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, int step, void* stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Depth network convolutions -- depth_estimation/networks.py:44-57,157-189,277-292             */
+/* fp32 implicit GEMM on v_mfma_f32_32x32x2_f32, NHWC activations.                               */
+/* ------------------------------------------------------------------------------------------ */
+#define E2E_ACT_NONE 0
+#define E2E_ACT_RELU 1
+#define E2E_ACT_ELU 2
+#define E2E_ACT_DISP 3   /* 10*sigmoid(x)+0.01 (networks.py:290) */
+
+/* torch weight (Cout,Cin,KH,KW) -> w_fwd [(kh,kw,ci)][ld_fwd] and/or w_bwd [(kh,kw,co)][ld_bwd]
+ * (k-major GEMM operands; the padding columns must have been zeroed by the caller). */
+int e2e_conv_weight_layouts(const float* w, int Cout, int Cin, int KH, int KW, float* w_fwd,
+                            int ld_fwd, float* w_bwd, int ld_bwd, void* stream);
+
+/* out (B,Ho,Wo,Cout) = act( scale[c] * conv(x) + shift[c] (+ residual) ), x = the VIRTUAL input
+ * cat( nearest_upsample(src0 (B,Hs/up,Ws/up,C1), up), src1 (B,Hs,Ws,Cin-C1) ) padded by `pad`
+ * (pad_mode 0 zeros, 1 reflection) -- upsample, concat and padding are gather arithmetic, never
+ * materialised (networks.py:283-287, :186-188).  scale/shift: folded eval-mode BatchNorm and/or
+ * bias (either may be NULL).  Cin % 16 != 0 (the RGB stem) takes a scalar-gather path that also
+ * applies (v - in_sub) * in_mul to the image (networks.py:50). */
+int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const float* w_fwd,
+                   int ld_fwd, const float* scale, const float* shift, const float* residual,
+                   float* out, int B, int Hs, int Ws, int Cin, int Cout, int KH, int KW, int stride,
+                   int pad, int pad_mode, int act, float in_sub, float in_mul, void* stream);
+
+/* dZ = dY * act'(Y) * scale[c]  (Y = the op's OUTPUT; scale may be NULL). */
+int e2e_conv2d_act_bwd(const float* dy, const float* y, const float* scale, float* dz, int64_t n,
+                       int C, int act, void* stream);
+
+/* gradient wrt the virtual (padded when pad_mode == 1) input: dxp (B,Hs+2p,Ws+2p,Cin). */
+int e2e_conv2d_bwd_data(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs,
+                        int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride,
+                        int pad, int pad_mode, void* stream);
+/* adjoint of the gather: dxp -> d_src0 (B,Hs/up,Ws/up,C1) [, d_src1 (B,Hs,Ws,Cin-C1)]; every output
+ * element sums its reflect-pad copies and its up x up readers in a fixed order (no atomics). */
+int e2e_conv2d_gather_adjoint(const float* dxp, int B, int Hs, int Ws, int Cin, int C1, int up,
+                              int padded, float* d_src0, float* d_src1, int accumulate0,
+                              int accumulate1, void* stream);
+
+/* dW (Cout,Cin,KH,KW) [and dbias (Cout) when non-NULL] = split-K GEMM over the output pixels with a
+ * fixed-order slab reduction.  workspace: e2e_conv2d_wgrad_workspace_floats(...) floats. */
+int64_t e2e_conv2d_wgrad_workspace_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW,
+                                          int has_bias);
+int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1, int C1, int up,
+                          float* dw, float* dbias, float* workspace, int B, int Hs, int Ws, int Cin,
+                          int Cout, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                          int pad_mode, int accumulate, float in_sub, float in_mul, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

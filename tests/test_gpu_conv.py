@@ -1,0 +1,87 @@
+"""Native fp32-MFMA convolution kernels against a float64 torch composition of the same operator
+(conv + folded eval-BN / bias + residual + activation over cat(upsample(x), skip) with zero / reflection padding)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref(x, skip, w, bias, scale, shift, res, up, stride, pad, pad_mode, act, in_norm):
+    x = x.double()
+    if in_norm is not None:
+        x = (x - in_norm[0]) * in_norm[1]
+    if up != 1:
+        x = F.interpolate(x, scale_factor=up, mode="nearest")
+    if skip is not None:
+        x = torch.cat([x, skip.double()], 1)
+    if pad_mode == "reflect" and pad:
+        x = F.pad(x, (pad,) * 4, mode="reflect")
+        y = F.conv2d(x, w.double(), None, stride, 0)
+    else:
+        y = F.conv2d(x, w.double(), None, stride, pad)
+    if scale is not None:
+        y = y * scale.double().view(1, -1, 1, 1)
+    if shift is not None:
+        y = y + shift.double().view(1, -1, 1, 1)
+    if bias is not None:
+        y = y + bias.double().view(1, -1, 1, 1)
+    if res is not None:
+        y = y + res.double()
+    if act == "relu":
+        y = F.relu(y)
+    elif act == "elu":
+        y = F.elu(y)
+    return y
+
+
+CASES = [
+    # B, Cin(x), Cskip, up, H,  W,  Cout, k, s, p, pad_mode, act,   bn,    bias,  res
+    (2, 64, 0, 1, 12, 20, 64, 3, 1, 1, "zeros", "relu", True, False, True),      # BasicBlock conv2 + residual
+    (2, 64, 0, 1, 12, 20, 128, 3, 2, 1, "zeros", "relu", True, False, False),     # stride-2 stage entry
+    (1, 64, 0, 1, 13, 9, 128, 1, 2, 0, "zeros", None, False, False, False),       # 1x1/2 downsample, odd sizes
+    (2, 3, 0, 1, 32, 48, 64, 7, 2, 3, "zeros", "relu", True, False, False),       # RGB stem (scalar gather + input normalisation)
+    (2, 512, 0, 1, 2, 3, 256, 3, 1, 1, "reflect", "elu", False, True, False),     # upconv(4,0) at the smallest size
+    (2, 256, 256, 2, 4, 6, 256, 3, 1, 1, "reflect", "elu", False, True, False),   # upconv(4,1): upsample + skip concat
+    (1, 32, 64, 2, 16, 24, 32, 3, 1, 1, "reflect", "elu", False, True, False),    # upconv(1,1): 96 input channels
+    (1, 32, 0, 1, 20, 36, 16, 3, 1, 1, "reflect", "elu", False, True, False),     # Cout = 16 (half MFMA tile)
+    (1, 16, 0, 2, 24, 40, 16, 3, 1, 1, "reflect", "elu", False, True, False),     # upconv(0,1): upsample without skip
+    (1, 128, 0, 1, 30, 40, 128, 3, 1, 1, "zeros", None, False, False, False),     # medium tile config
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"c{i}" for i in range(len(CASES))])
+def test_conv_forward_backward(case):
+    from e2ehip import conv
+    B, Cx, Cs, up, H, W, Cout, k, s, p, pad_mode, act, bn, use_bias, use_res = case
+    g = torch.Generator().manual_seed(sum(case[:7]))
+    rnd = lambda *shape: torch.randn(*shape, generator=g)
+    x = rnd(B, Cx, H // up if up > 1 else H, W // up if up > 1 else W).to(DEV).contiguous(memory_format=torch.channels_last)
+    if up > 1:
+        H, W = x.shape[2] * up, x.shape[3] * up
+    skip = rnd(B, Cs, H, W).to(DEV).contiguous(memory_format=torch.channels_last) if Cs else None
+    Cin = Cx + Cs
+    w = (rnd(Cout, Cin, k, k) / (Cin * k * k) ** 0.5).to(DEV)
+    bias = rnd(Cout).to(DEV) if use_bias else None
+    scale = (rnd(Cout).abs() + 0.5).to(DEV) if bn else None
+    shift = rnd(Cout).to(DEV) if bn else None
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    res = rnd(B, Cout, Ho, Wo).to(DEV).contiguous(memory_format=torch.channels_last) if use_res else None
+    in_norm = (0.45, 1 / 0.225) if Cx == 3 else None
+    leaves = [t for t in (x, skip, w, bias, res) if t is not None]
+    stem = Cx == 3
+    for t in leaves:
+        t.requires_grad_(not (stem and t is x))
+    y = conv.conv2d(x, w, bias, s, p, pad_mode, act, (scale, shift) if bn else None, res, skip, up, in_norm)
+    yr = _ref(x, skip, w, bias, scale, shift, res, up, s, p, pad_mode, act, in_norm)
+    assert tuple(y.shape) == tuple(yr.shape)
+    err = ((y.double() - yr).abs().max() / yr.abs().max()).item()
+    assert err < 2e-5, f"forward: {err:.2e}"
+    gy = rnd(*y.shape).to(DEV)
+    diff = [t for t in leaves if t.requires_grad]
+    grads = torch.autograd.grad(y, diff, gy, retain_graph=False)
+    grads_r = torch.autograd.grad(yr, diff, gy.double())
+    for t, a, b in zip(diff, grads, grads_r):
+        e = ((a.double() - b).abs().max() / (b.abs().max() + 1e-30)).item()
+        assert e < 5e-5, f"grad of tensor {tuple(t.shape)}: {e:.2e}"
