@@ -42,6 +42,10 @@ struct ConvArgs {
     int off;               // backward-data: offset added to (yd,xd) to get padded-domain coordinates
     int act;
     float in_sub, in_mul;  // VEC==1 path only: gathered value -> (v - in_sub) * in_mul  (input normalisation, networks.py:50)
+    // split-K (layers with few output tiles): grid.z slices of `cps` chunks write raw accumulators to slab[z][n][Ncols];
+    // k_conv_splitk_epilogue adds the slices in order and applies the epilogue.  ksplit == 1: direct epilogue.
+    int ksplit, cps;
+    float* slab;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -94,7 +98,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     const int64_t n0 = (int64_t)blockIdx.x * BM;
     const int c0 = blockIdx.y * BN;
     const int K = a.KH * a.KW * a.Cin;
-    const int nchunks = (K + CBK - 1) / CBK;
+    const int nchunks_all = (K + CBK - 1) / CBK;
+    const int cbeg = (a.ksplit > 1) ? blockIdx.z * a.cps : 0;
+    const int cend = (a.ksplit > 1) ? min(nchunks_all, cbeg + a.cps) : nchunks_all;
 
     // ---- per-thread A row (fixed for the whole K loop) --------------------------------------------------------------
     const int arow = tid % BM;
@@ -114,27 +120,51 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     float areg1[A_PER];
     f4v breg[B_PER];
 
+    // VEC == 4: the K loop is walked tap-major.  The gather coordinates of this thread's row change only when the
+    // tap changes (every Cin/16 chunks), so the div/mod decode, reflection and pointer selection are hoisted out of
+    // the chunk loop: per chunk the address is (tap pointer) + channel offset.
+    const int cpt = (VEC == 4) ? a.Cin / CBK : 1;          // chunks per tap
+    int ld_tap = -1, ld_cc = 0;                              // state of the LOAD stream (runs one chunk ahead)
+    const float* tp0 = nullptr;
+    const float* tp1 = nullptr;
+    auto next_tap = [&]() {
+        ++ld_tap;
+        ld_cc = 0;
+        tp0 = tp1 = nullptr;
+        if (arow_ok && ld_tap < a.KH * a.KW) {
+            const int kh = ld_tap / a.KW, kw = ld_tap - kh * a.KW;
+            int ys, xs;
+            if (tap_coord<TRANSPOSED>(a, ayd, axd, kh, kw, ys, xs)) {
+                tp0 = a.src0 + (((int64_t)ab * Hl + ys / a.up) * Wl + xs / a.up) * a.C1;
+                if (C2 > 0) tp1 = a.src1 + (((int64_t)ab * a.Hs + ys) * a.Ws + xs) * C2 - a.C1;   // indexed by ci directly
+            }
+        }
+    };
+    if (VEC == 4) {                                          // position the load stream on chunk `cbeg`
+        ld_tap = cbeg / cpt - 1;
+        next_tap();
+        ld_cc = cbeg - (cbeg / cpt) * cpt;
+    }
+
     auto load_chunk = [&](int chunk) {
         const int kbase = chunk * CBK;
+        if (VEC == 4) {
 #pragma unroll
-        for (int j = 0; j < A_PER; ++j) {
-            const int kq = akq0 + j * (NT / BM);
-            if (VEC == 4) {
-                const int k = kbase + kq * 4;                // Cin % 16 == 0: the quad never straddles a tap or the concat split
+            for (int j = 0; j < A_PER; ++j) {
+                const int kq = akq0 + j * (NT / BM);
                 f4v v = (f4v){0.f, 0.f, 0.f, 0.f};
-                if (arow_ok && kq < KQ && k < K) {
-                    const int tap = k / a.Cin, ci = k - tap * a.Cin;
-                    const int kh = tap / a.KW, kw = tap - kh * a.KW;
-                    int ys, xs;
-                    if (tap_coord<TRANSPOSED>(a, ayd, axd, kh, kw, ys, xs)) {
-                        const float* p = (ci < a.C1)
-                            ? a.src0 + (((int64_t)ab * Hl + ys / a.up) * Wl + xs / a.up) * a.C1 + ci
-                            : a.src1 + (((int64_t)ab * a.Hs + ys) * a.Ws + xs) * C2 + (ci - a.C1);
-                        v = *(const f4v*)p;
-                    }
+                if (kq < KQ) {
+                    const int ci = ld_cc * CBK + kq * 4;      // Cin % 16 == 0: a quad never straddles a tap or the concat split
+                    const float* p = (ci < a.C1) ? tp0 : tp1;
+                    if (p) v = *(const f4v*)(p + ci);
                 }
                 areg[j] = v;
-            } else {
+            }
+            if (++ld_cc == cpt) next_tap();
+        } else {
+#pragma unroll
+            for (int j = 0; j < A_PER; ++j) {
+                const int kq = akq0 + j * (NT / BM);
                 const int k = kbase + kq;
                 float v = 0.f;
                 if (arow_ok && kq < KQ && k < K) {
@@ -184,13 +214,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    load_chunk(0);
-    store_chunk(0);
+    if (cbeg < cend) {
+        load_chunk(cbeg);
+        store_chunk(0);
+    }
     __syncthreads();
     const int arow_l = wm * 32 + (lane & 31), khalf = lane >> 5;
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) load_chunk(c + 1);             // global loads in flight under the MFMAs below
+    for (int c = cbeg; c < cend; ++c) {
+        const int buf = (c - cbeg) & 1;
+        if (c + 1 < cend) load_chunk(c + 1);                // global loads in flight under the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < CBK / 2; ++kk) {
             const float av = As[buf][kk * 2 + khalf][arow_l];
@@ -200,10 +232,24 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
             }
         }
-        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        if (c + 1 < cend) store_chunk(buf ^ 1);
         __syncthreads();
     }
 
+    if (a.ksplit > 1) {                                      // raw partial sums; the epilogue runs after the reduction
+        float* slab = a.slab + (int64_t)blockIdx.z * Ntot * a.Ncols;
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int col = c0 + (wn * TN + t) * 32 + (lane & 31);
+            if (col >= a.Ncols) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t n = n0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (n < Ntot) slab[n * a.Ncols + col] = acc[t][r];
+            }
+        }
+        return;
+    }
     // ---- epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5) ----------------------------
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
@@ -218,6 +264,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
             if (a.res) v += a.res[n * a.Ncols + col];
             a.out[n * a.Ncols + col] = apply_act(v, a.act);
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_conv_splitk_epilogue(const float* __restrict__ slab, int S, int64_t total, int Ncols,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const float* __restrict__ res, float* __restrict__ out, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int z = 0; z < S; ++z) v += slab[(int64_t)z * total + i];        // fixed order
+        const int col = (int)(i % Ncols);
+        v = fmaf(v, scale ? scale[col] : 1.f, shift ? shift[col] : 0.f);
+        if (res) v += res[i];
+        out[i] = apply_act(v, act);
     }
 }
 
@@ -242,70 +301,88 @@ struct WgradArgs {
     int vec;
 };
 
-template <int VEC>
+template <int WM, int WN, int VEC>
 __global__ __launch_bounds__(256) void k_wgrad_gemm(WgradArgs a) {
-    constexpr int BM = 64, BN = 64, NT = 256;              // 2x2 waves of 32x32
+    constexpr int BM = 32 * WM, BN = 32 * WN, NT = 256;     // WM x WN = 4 waves, one 32x32 accumulator each
+    constexpr int A_CNT = CBK * (BM / 4), B_CNT = CBK * (BN / 4);
+    constexpr int A_PER = (A_CNT + NT - 1) / NT, B_PER = (B_CNT + NT - 1) / NT;
     __shared__ float As[2][CBK][BM];
     __shared__ float Bs[2][CBK][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % WM, wn = wave / WM;
     const int m0 = blockIdx.y * BM, nn0 = blockIdx.x * BN;
     const int64_t P = (int64_t)a.B * a.Ho * a.Wo;
     const int64_t p0 = (int64_t)blockIdx.z * a.pix_per_slice;
     const int64_t p1 = (p0 + a.pix_per_slice < P) ? p0 + a.pix_per_slice : P;
-    const int nchunks = (int)((p1 - p0 + CBK - 1) / CBK);
+    const int nchunks = (p1 > p0) ? (int)((p1 - p0 + CBK - 1) / CBK) : 0;
     const int Hl = a.Hs / a.up, Wl = a.Ws / a.up, C2 = a.Cin - a.C1;
     const int Kconv = a.KH * a.KW * a.Cin;
 
-    // A tile: CBK pixels x 64 couts = 256 float4 -> one per thread.  B tile: CBK pixels x 64 n-columns.
-    const int a_kr = tid / (BM / 4), a_mq = tid % (BM / 4);
-    const int b_kr = tid / (BN / 4), b_nq = tid % (BN / 4);
-    // this thread's B column quad is fixed over the K loop: decode (tap, ci) once
-    const int ncol = nn0 + b_nq * 4;
-    int tap = 0, ci = 0, kh = 0, kw = 0;
-    const bool col_conv = ncol < Kconv;
-    if (col_conv && VEC == 4) { tap = ncol / a.Cin; ci = ncol - tap * a.Cin; kh = tap / a.KW; kw = tap - kh * a.KW; }
-
-    f4v areg, breg;
-    auto load_chunk = [&](int chunk) {
-        {
-            const int64_t p = p0 + (int64_t)chunk * CBK + a_kr;
-            const int m = m0 + a_mq * 4;
+    // per-thread fixed roles.  B: (pixel row kr inside the chunk, column quad) -> the column's (tap, ci) is decoded ONCE and
+    // the pixel (b,oh,ow) is advanced incrementally by CBK per chunk (no divisions in the loop).
+    int b_kr[B_PER], b_col[B_PER], b_kh[B_PER], b_kw[B_PER], b_ci[B_PER];
+    int pb[B_PER], poh[B_PER], pow_[B_PER];
+    bool b_on[B_PER], b_conv[B_PER];
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+        const int idx = tid + j * NT;
+        b_on[j] = idx < B_CNT;
+        b_kr[j] = idx / (BN / 4);
+        b_col[j] = nn0 + (idx - b_kr[j] * (BN / 4)) * 4;
+        b_conv[j] = b_col[j] < Kconv;
+        const int tap = b_conv[j] ? b_col[j] / a.Cin : 0;
+        b_ci[j] = b_conv[j] ? b_col[j] - tap * a.Cin : 0;
+        b_kh[j] = tap / a.KW;
+        b_kw[j] = tap - b_kh[j] * a.KW;
+        const int64_t p = p0 + b_kr[j];
+        pb[j] = (int)(p / ((int64_t)a.Ho * a.Wo));
+        const int r = (int)(p - (int64_t)pb[j] * a.Ho * a.Wo);
+        poh[j] = r / a.Wo;
+        pow_[j] = r - poh[j] * a.Wo;
+    }
+    f4v areg[A_PER], breg[B_PER];
+    int ld_chunk = 0;
+    auto load_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            const int idx = tid + j * NT;
+            const int kr = idx / (BM / 4), m = m0 + (idx - kr * (BM / 4)) * 4;
+            const int64_t p = p0 + (int64_t)ld_chunk * CBK + kr;
             f4v v = (f4v){0.f, 0.f, 0.f, 0.f};
-            if (p < p1 && m < a.Cout) {
+            if (idx < A_CNT && p < p1 && m < a.Cout) {
                 if (a.Cout % 4 == 0) v = *(const f4v*)(a.dz + p * a.Cout + m);
                 else
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (m + e < a.Cout) v[e] = a.dz[p * a.Cout + m + e];
             }
-            areg = v;
+            areg[j] = v;
         }
-        {
-            const int64_t p = p0 + (int64_t)chunk * CBK + b_kr;
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int64_t p = p0 + (int64_t)ld_chunk * CBK + b_kr[j];
             f4v v = (f4v){0.f, 0.f, 0.f, 0.f};
-            if (p < p1) {
-                const int b = (int)(p / ((int64_t)a.Ho * a.Wo));
-                const int r = (int)(p - (int64_t)b * a.Ho * a.Wo);
-                const int oh = r / a.Wo, ow = r - oh * a.Wo;
+            if (b_on[j] && p < p1) {
+                const int b = pb[j], oh = poh[j], ow = pow_[j];
                 if (VEC == 4) {
-                    if (col_conv) {
-                        int ys = oh * a.stride + kh - a.pad, xs = ow * a.stride + kw - a.pad;
+                    if (b_conv[j]) {
+                        int ys = oh * a.stride + b_kh[j] - a.pad, xs = ow * a.stride + b_kw[j] - a.pad;
                         bool ok = true;
                         if (a.pad_mode == 1) { ys = reflect1(ys, a.Hs); xs = reflect1(xs, a.Ws); }
                         else ok = ys >= 0 && ys < a.Hs && xs >= 0 && xs < a.Ws;
                         if (ok) {
+                            const int ci = b_ci[j];
                             const float* q = (ci < a.C1)
                                 ? a.src0 + (((int64_t)b * Hl + ys / a.up) * Wl + xs / a.up) * a.C1 + ci
                                 : a.src1 + (((int64_t)b * a.Hs + ys) * a.Ws + xs) * C2 + (ci - a.C1);
                             v = *(const f4v*)q;
                         }
-                    } else if (a.has_bias && ncol == Kconv) {
+                    } else if (a.has_bias && b_col[j] == Kconv) {
                         v[0] = 1.f;                            // ones column: dW[:, Kconv] = sum_p dZ = bias gradient
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int n = ncol + e;
+                        const int n = b_col[j] + e;
                         if (n < Kconv) {
                             const int tp = n / a.Cin, c = n - tp * a.Cin, kh1 = tp / a.KW, kw1 = tp - kh1 * a.KW;
                             const int ys = oh * a.stride + kh1 - a.pad, xs = ow * a.stride + kw1 - a.pad;
@@ -315,25 +392,41 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm(WgradArgs a) {
                     }
                 }
             }
-            breg = v;
+            breg[j] = v;
+            // advance this role's pixel by one chunk
+            pow_[j] += CBK;
+            while (pow_[j] >= a.Wo) { pow_[j] -= a.Wo; if (++poh[j] == a.Ho) { poh[j] = 0; ++pb[j]; } }
         }
+        ++ld_chunk;
     };
     auto store_chunk = [&](int buf) {
-        *(f4v*)&As[buf][a_kr][a_mq * 4] = areg;
-        *(f4v*)&Bs[buf][b_kr][b_nq * 4] = breg;
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            const int idx = tid + j * NT;
+            if (idx >= A_CNT) continue;
+            const int kr = idx / (BM / 4), mq = idx - kr * (BM / 4);
+            *(f4v*)&As[buf][kr][mq * 4] = areg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int idx = tid + j * NT;
+            if (idx >= B_CNT) continue;
+            const int nq = idx - b_kr[j] * (BN / 4);
+            *(f4v*)&Bs[buf][b_kr[j]][nq * 4] = breg[j];
+        }
     };
     f16v acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (nchunks > 0) {
-        load_chunk(0);
+        load_chunk();
         store_chunk(0);
     }
     __syncthreads();
     const int khalf = lane >> 5;
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunks) load_chunk(c + 1);
+        if (c + 1 < nchunks) load_chunk();
 #pragma unroll
         for (int kk = 0; kk < CBK / 2; ++kk) {
             const float av = As[buf][kk * 2 + khalf][wm * 32 + (lane & 31)];
@@ -349,6 +442,28 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm(WgradArgs a) {
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
         if (m < a.Mpad && n < a.Npad) slab[(int64_t)m * a.Npad + n] = acc[r];
+    }
+}
+
+// fold groups of FOLD consecutive slabs into one (fixed order inside a group, groups stay in order): turns the serial
+// S-long sum of the final pass into a two-level tree with S/FOLD-fold more parallelism
+#define WG_FOLD 16
+__global__ __launch_bounds__(256) void k_slab_fold(const float* __restrict__ in, int S, int64_t slab_elems, float* __restrict__ out) {
+    const int groups = (S + WG_FOLD - 1) / WG_FOLD;
+    const int64_t total = slab_elems * groups;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int gq = (int)(i / slab_elems);
+        const int64_t e = i - (int64_t)gq * slab_elems;
+        float v[WG_FOLD];
+#pragma unroll
+        for (int j = 0; j < WG_FOLD; ++j) {
+            const int z = gq * WG_FOLD + j;
+            v[j] = (z < S) ? in[(int64_t)z * slab_elems + e] : 0.f;     // independent loads, issued together
+        }
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < WG_FOLD; ++j) sacc += v[j];
+        out[i] = sacc;
     }
 }
 
@@ -449,9 +564,35 @@ __global__ __launch_bounds__(256) void k_gather_adjoint(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------------------------
 static inline int egrid(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
+// split-K factor for a GEMM of Ntot rows x Ncols columns x K: only when the 64x64 tiling leaves most CUs idle
+static int splitk_factor(int64_t Ntot, int Ncols, int K, int vec) {
+    if (vec != 4 || Ncols < 64) return 1;
+    const int64_t tiles = ((Ntot + 63) / 64) * ((Ncols + 63) / 64);
+    if (tiles >= 384) return 1;
+    const int nchunks = (K + CBK - 1) / CBK;
+    int64_t S = 768 / tiles;
+    if (S > 8) S = 8;
+    if (S > nchunks / 8) S = nchunks / 8;                  // at least 8 chunks (128 k) per slice
+    return S < 2 ? 1 : (int)S;
+}
+
 template <bool TR>
-static void launch_gemm(const ConvArgs& a, int vec, hipStream_t st) {
+static void launch_gemm(ConvArgs a, int vec, float* workspace, hipStream_t st) {
     const int64_t Ntot = (int64_t)a.B * a.Hd * a.Wd;
+    const int K = a.KH * a.KW * a.Cin;
+    const int S = workspace ? splitk_factor(Ntot, a.Ncols, K, vec) : 1;
+    a.ksplit = S; a.cps = 0; a.slab = workspace;
+    if (S > 1) {
+        const int nchunks = (K + CBK - 1) / CBK;
+        a.cps = (nchunks + S - 1) / S;
+        const int Sz = (nchunks + a.cps - 1) / a.cps;
+        a.ksplit = Sz;
+        dim3 g((unsigned)((Ntot + 63) / 64), (unsigned)((a.Ncols + 63) / 64), (unsigned)Sz);
+        hipLaunchKernelGGL((k_conv_gemm<2, 2, 1, 4, TR>), g, dim3(256), 0, st, a);
+        const int64_t total = Ntot * a.Ncols;
+        hipLaunchKernelGGL(k_conv_splitk_epilogue, dim3(egrid(total)), dim3(256), 0, st, workspace, Sz, total, a.Ncols, a.scale, a.shift, a.res, a.out, a.act);
+        return;
+    }
     if (vec == 1) {
         dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 63) / 64));
         hipLaunchKernelGGL((k_conv_gemm<4, 1, 2, 1, TR>), g, dim3(256), 0, st, a);
@@ -487,9 +628,15 @@ int e2e_conv_weight_layouts(const float* w, int Cout, int Cin, int KH, int KW, f
     return E2E_OK;
 }
 
+/* floats of split-K workspace a GEMM of `rows` x `cols` with reduction length K may use (0: never splits) */
+int64_t e2e_conv2d_splitk_workspace_floats(int64_t rows, int cols, int K) {
+    const int S = splitk_factor(rows, cols, K, (K % 16 == 0) ? 4 : 1);
+    return S > 1 ? (int64_t)S * rows * cols : 0;
+}
+
 int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const float* w_fwd, int ld_fwd, const float* scale,
                    const float* shift, const float* residual, float* out, int B, int Hs, int Ws, int Cin, int Cout, int KH,
-                   int KW, int stride, int pad, int pad_mode, int act, float in_sub, float in_mul, void* stream) {
+                   int KW, int stride, int pad, int pad_mode, int act, float in_sub, float in_mul, float* workspace, void* stream) {
     E2E_REQUIRE(src0 && w_fwd && out && B > 0 && Hs > 0 && Ws > 0 && Cin > 0 && Cout > 0, E2E_ERR_ARG, "e2e_conv2d_fwd: bad argument");
     E2E_REQUIRE(up == 1 || up == 2, E2E_ERR_ARG, "e2e_conv2d_fwd: upsample factor must be 1 or 2");
     E2E_REQUIRE(C1 > 0 && C1 <= Cin && (C1 == Cin || src1), E2E_ERR_ARG, "e2e_conv2d_fwd: bad channel split");
@@ -504,13 +651,13 @@ int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const f
     a.Hd = (Hs + 2 * pad - KH) / stride + 1; a.Wd = (Ws + 2 * pad - KW) / stride + 1;
     a.Ncols = Cout; a.ldw = ld_fwd; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_mode = pad_mode; a.off = 0; a.act = act;
     a.in_sub = in_sub; a.in_mul = in_mul;
-    launch_gemm<false>(a, vec, (hipStream_t)stream);
+    launch_gemm<false>(a, vec, workspace, (hipStream_t)stream);
     E2E_LAUNCH_CHECK("e2e_conv2d_fwd");
     return E2E_OK;
 }
 
 int e2e_conv2d_bwd_data(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout,
-                        int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, void* stream) {
+                        int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, float* workspace, void* stream) {
     E2E_REQUIRE(dz && w_bwd && dxp && B > 0 && Cin > 0 && Cout > 0 && Cout % 16 == 0, E2E_ERR_ARG, "e2e_conv2d_bwd_data: bad argument (Cout %% 16 == 0)");
     E2E_REQUIRE(ld_bwd % 4 == 0 && ld_bwd >= Cin && (stride == 1 || stride == 2), E2E_ERR_ARG, "e2e_conv2d_bwd_data: bad sizes");
     ConvArgs a{};
@@ -519,7 +666,7 @@ int e2e_conv2d_bwd_data(const float* dz, const float* w_bwd, int ld_bwd, float* 
     const int pp = pad_mode == 1 ? pad : 0;                // reflect: produce the whole padded domain, folded afterwards
     a.Hd = Hs + 2 * pp; a.Wd = Ws + 2 * pp; a.off = pad_mode == 1 ? 0 : pad;
     a.Ncols = Cin; a.ldw = ld_bwd; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_mode = 0; a.act = ACT_NONE;
-    launch_gemm<true>(a, 4, (hipStream_t)stream);
+    launch_gemm<true>(a, 4, workspace, (hipStream_t)stream);
     E2E_LAUNCH_CHECK("e2e_conv2d_bwd_data");
     return E2E_OK;
 }
@@ -544,14 +691,16 @@ int e2e_conv2d_act_bwd(const float* dy, const float* y, const float* scale, floa
 
 int64_t e2e_conv2d_wgrad_workspace_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int has_bias) {
     const int Ng = KH * KW * Cin + (has_bias ? 1 : 0);
-    const int Mpad = (Cout + 63) / 64 * 64, Npad = (Ng + 63) / 64 * 64;
+    const int tm = Cout <= 32 ? 32 : 64, tn = Cout <= 32 ? 128 : 64;         // 32x128 tiles for the thin layers
+    const int Mpad = (Cout + tm - 1) / tm * tm, Npad = (Ng + tn - 1) / tn * tn;
     const int64_t P = (int64_t)B * Ho * Wo;
-    const int64_t tiles = (int64_t)(Mpad / 64) * (Npad / 64);
+    const int64_t tiles = (int64_t)(Mpad / tm) * (Npad / tn);
     int64_t S = (1024 + tiles - 1) / tiles;                 // ~4 workgroups per CU in total
     const int64_t maxS = (P + 255) / 256;                   // at least 256 pixels per slice
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
-    return S * Mpad * Npad;
+    const int64_t folded = (S > WG_FOLD) ? (S + WG_FOLD - 1) / WG_FOLD : 0;
+    return (S + folded) * Mpad * Npad;
 }
 
 int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1, int C1, int up, float* dw, float* dbias,
@@ -565,17 +714,43 @@ int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1,
     a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cin = Cin; a.C1 = C1; a.up = up; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_mode = pad_mode; a.has_bias = dbias ? 1 : 0;
     a.Ngemm = KH * KW * Cin + a.has_bias;
-    a.Mpad = (Cout + 63) / 64 * 64; a.Npad = (a.Ngemm + 63) / 64 * 64;
+    const int tm = Cout <= 32 ? 32 : 64, tn = Cout <= 32 ? 128 : 64;
+    a.Mpad = (Cout + tm - 1) / tm * tm; a.Npad = (a.Ngemm + tn - 1) / tn * tn;
     a.in_sub = in_sub; a.in_mul = in_mul; a.vec = vec;
     const int64_t P = (int64_t)B * Ho * Wo;
-    const int64_t S = e2e_conv2d_wgrad_workspace_floats(B, Ho, Wo, Cin, Cout, KH, KW, a.has_bias) / ((int64_t)a.Mpad * a.Npad);
+    int64_t S = e2e_conv2d_wgrad_workspace_floats(B, Ho, Wo, Cin, Cout, KH, KW, a.has_bias) / ((int64_t)a.Mpad * a.Npad);
+    if (S > WG_FOLD) S = (S * WG_FOLD + WG_FOLD) / (WG_FOLD + 1) > 0 ? S - (S + WG_FOLD) / (WG_FOLD + 1) : S;   // strip the fold area
+    {   // recompute S exactly as the workspace function does (the division above only bounds it)
+        const int tm0 = Cout <= 32 ? 32 : 64, tn0 = Cout <= 32 ? 128 : 64;
+        const int64_t tiles0 = (int64_t)(a.Mpad / tm0) * (a.Npad / tn0);
+        const int64_t P0 = (int64_t)B * Ho * Wo;
+        S = (1024 + tiles0 - 1) / tiles0;
+        const int64_t maxS = (P0 + 255) / 256;
+        if (S > maxS) S = maxS;
+        if (S < 1) S = 1;
+    }
     a.pix_per_slice = ((P + S - 1) / S + CBK - 1) / CBK * CBK;
     const int Sz = (int)((P + a.pix_per_slice - 1) / a.pix_per_slice);
-    dim3 g((unsigned)(a.Npad / 64), (unsigned)(a.Mpad / 64), (unsigned)Sz);
+    dim3 g((unsigned)(a.Npad / tn), (unsigned)(a.Mpad / tm), (unsigned)Sz);
     hipStream_t st = (hipStream_t)stream;
-    if (vec == 4) hipLaunchKernelGGL(k_wgrad_gemm<4>, g, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_wgrad_gemm<1>, g, dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(egrid((int64_t)Cout * a.Ngemm)), dim3(256), 0, st, workspace, Sz, a.Mpad, a.Npad, Cout, Cin, KH,
+    if (tm == 32) {
+        if (vec == 4) hipLaunchKernelGGL((k_wgrad_gemm<1, 4, 4>), g, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_wgrad_gemm<1, 4, 1>), g, dim3(256), 0, st, a);
+    } else {
+        if (vec == 4) hipLaunchKernelGGL((k_wgrad_gemm<2, 2, 4>), g, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_wgrad_gemm<2, 2, 1>), g, dim3(256), 0, st, a);
+    }
+    const float* red_in = workspace;
+    int red_S = Sz;
+    if (Sz > WG_FOLD) {
+        float* folded = workspace + S * (int64_t)a.Mpad * a.Npad;
+        const int64_t elems = (int64_t)a.Mpad * a.Npad;
+        const int groups = (Sz + WG_FOLD - 1) / WG_FOLD;
+        hipLaunchKernelGGL(k_slab_fold, dim3(egrid(elems * groups)), dim3(256), 0, st, workspace, Sz, elems, folded);
+        red_in = folded;
+        red_S = groups;
+    }
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(egrid((int64_t)Cout * a.Ngemm)), dim3(256), 0, st, red_in, red_S, a.Mpad, a.Npad, Cout, Cin, KH,
                        KW, a.has_bias, dw, dbias, accumulate);
     E2E_LAUNCH_CHECK("e2e_conv2d_bwd_weight");
     return E2E_OK;

@@ -61,8 +61,10 @@ class _Conv2d(torch.autograd.Function):
             residual = _cl(L.dev(residual, "residual"))
         out = torch.empty(B, Cout, Ho, Wo, device=dev, dtype=torch.float32, memory_format=CL)
         isub, imul = in_norm if in_norm is not None else (0.0, 1.0)
+        nws = L.load().e2e_conv2d_splitk_workspace_floats(B * Ho * Wo, Cout, KH * KW * Cin)
+        ws = torch.empty(nws, device=dev, dtype=torch.float32) if nws else None
         L.call("e2e_conv2d_fwd", L.ptr(src0), L.ptr(src1), C1, up, L.ptr(wf), ldf, L.ptr(scale), L.ptr(sh), L.ptr(residual), L.ptr(out),
-               B, Hs, Ws, Cin, Cout, KH, KW, stride, pad, pad_mode, act, float(isub), float(imul), L.stream())
+               B, Hs, Ws, Cin, Cout, KH, KW, stride, pad, pad_mode, act, float(isub), float(imul), L.ptr(ws), L.stream())
         ctx.save_for_backward(src0, src1, wb, scale, out)
         ctx.cfg = (B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, act, up, C1, ldb, float(isub), float(imul),
                    bias is not None, residual is not None)
@@ -97,7 +99,10 @@ class _Conv2d(torch.autograd.Function):
             pp = pad if pad_mode == 1 else 0
             direct = pp == 0 and up == 1 and src1 is None
             dxp = torch.empty(B, Cin, Hs + 2 * pp, Ws + 2 * pp, device=dev, dtype=torch.float32, memory_format=CL)
-            L.call("e2e_conv2d_bwd_data", L.ptr(dZ), L.ptr(wb), ldb, L.ptr(dxp), B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, st)
+            nws = L.load().e2e_conv2d_splitk_workspace_floats(B * (Hs + 2 * pp) * (Ws + 2 * pp), Cin, KH * KW * Cout)
+            ws2 = torch.empty(nws, device=dev, dtype=torch.float32) if nws else None
+            L.call("e2e_conv2d_bwd_data", L.ptr(dZ), L.ptr(wb), ldb, L.ptr(dxp), B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode,
+                   L.ptr(ws2), st)
             if direct:
                 g0 = dxp
             else:

@@ -279,7 +279,12 @@ int e2e_conv_weight_layouts(const float* w, int Cout, int Cin, int KH, int KW, f
 int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const float* w_fwd,
                    int ld_fwd, const float* scale, const float* shift, const float* residual,
                    float* out, int B, int Hs, int Ws, int Cin, int Cout, int KH, int KW, int stride,
-                   int pad, int pad_mode, int act, float in_sub, float in_mul, void* stream);
+                   int pad, int pad_mode, int act, float in_sub, float in_mul, float* workspace,
+                   void* stream);
+/* Layers with few output tiles (deep, small-spatial) split the reduction over workgroups and add the
+ * slices in a fixed order.  workspace for e2e_conv2d_fwd (rows = B*Ho*Wo, cols = Cout, K = KH*KW*Cin)
+ * and e2e_conv2d_bwd_data (rows = B*(Hs+2p)*(Ws+2p), cols = Cin, K = KH*KW*Cout); NULL disables it. */
+int64_t e2e_conv2d_splitk_workspace_floats(int64_t rows, int cols, int K);
 
 /* dZ = dY * act'(Y) * scale[c]  (Y = the op's OUTPUT; scale may be NULL). */
 int e2e_conv2d_act_bwd(const float* dy, const float* y, const float* scale, float* dz, int64_t n,
@@ -288,7 +293,7 @@ int e2e_conv2d_act_bwd(const float* dy, const float* y, const float* scale, floa
 /* gradient wrt the virtual (padded when pad_mode == 1) input: dxp (B,Hs+2p,Ws+2p,Cin). */
 int e2e_conv2d_bwd_data(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs,
                         int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride,
-                        int pad, int pad_mode, void* stream);
+                        int pad, int pad_mode, float* workspace, void* stream);
 /* adjoint of the gather: dxp -> d_src0 (B,Hs/up,Ws/up,C1) [, d_src1 (B,Hs,Ws,Cin-C1)]; every output
  * element sums its reflect-pad copies and its up x up readers in a fixed order (no atomics). */
 int e2e_conv2d_gather_adjoint(const float* dxp, int B, int Hs, int Ws, int Cin, int C1, int up,

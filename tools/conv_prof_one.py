@@ -1,0 +1,18 @@
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "end-to-end-self-supervised-slam_amd")]
+from e2ehip import nn_ops
+DEV = "cuda:0"
+cases = {"up01": (16, 0, 2, 480, 640, 16, 3, 1, 1, "reflect", "elu"), "layer1": (64, 0, 1, 120, 160, 64, 3, 1, 1, "zeros", "relu"),
+         "up11": (32, 64, 2, 240, 320, 32, 3, 1, 1, "reflect", "elu"), "l2s2": (64, 0, 1, 120, 160, 128, 3, 2, 1, "zeros", "relu")}
+Cx, Cs, up, H, W, Cout, k, s, p, pm, act = cases[sys.argv[1]]
+B = 2
+x = torch.randn(B, Cx, H // up, W // up, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+skip = torch.randn(B, Cs, H, W, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True) if Cs else None
+w = (torch.randn(Cout, Cx + Cs, k, k, device=DEV) * 0.05).requires_grad_(True)
+bias = torch.randn(Cout, device=DEV).requires_grad_(True) if pm == "reflect" else None
+leaves = [t for t in (x, skip, w, bias) if t is not None]
+for _ in range(12):
+    y = nn_ops.conv2d(x, w, bias, s, p, pm, act, None, None, skip, up, None)
+    torch.autograd.grad(y, leaves, torch.ones_like(y))
+torch.cuda.synchronize()
