@@ -560,6 +560,119 @@ __global__ __launch_bounds__(256) void k_gather_adjoint(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The 1-channel disparity head (networks.py:271-272,289-290): Conv3x3(reflect) 16 -> 1 + 10*sigmoid+0.01.  One output
+// column cannot fill an MFMA tile; it is a 144-tap dot product per pixel -- HBM-bound VALU kernels.
+// ---------------------------------------------------------------------------------------------------------------------
+#define HC 16   // input channels of the head this kernel family is specialised for (num_ch_dec[0], networks.py:253)
+__global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ x, const float* __restrict__ w /*(1,16,3,3)*/,
+                                                  const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W, int act) {
+    __shared__ float sw[9 * HC];
+    for (int i = threadIdx.x; i < 9 * HC; i += 256) {        // (ci,kh,kw) -> [tap][ci]
+        const int ci = i / 9, tap = i - ci * 9;
+        sw[tap * HC + ci] = w[i];
+    }
+    __syncthreads();
+    const int64_t N = (int64_t)B * H * W;
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+        const int b = (int)(n / ((int64_t)H * W));
+        const int r = (int)(n - (int64_t)b * H * W), h = r / W, ww = r - h * W;
+        float acc = bias ? bias[0] : 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ys = reflect1(h + kh - 1, H), xs = reflect1(ww + kw - 1, W);
+                const f4v* p = (const f4v*)(x + (((int64_t)b * H + ys) * W + xs) * HC);
+                const float* wt = &sw[(kh * 3 + kw) * HC];
+#pragma unroll
+                for (int q = 0; q < HC / 4; ++q) {
+                    const f4v v = p[q];
+                    acc = fmaf(v[0], wt[q * 4], fmaf(v[1], wt[q * 4 + 1], fmaf(v[2], wt[q * 4 + 2], fmaf(v[3], wt[q * 4 + 3], acc))));
+                }
+            }
+        y[n] = apply_act(acc, act);
+    }
+}
+
+// d/dx: every input pixel gathers the (reflect-aware) outputs that read it:  dx[p,ci] = sum_{q, tap: src(q,tap)=p} dz[q] w[tap,ci]
+__global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ dx,
+                                                       int B, int H, int W) {
+    __shared__ float sw[9 * HC];
+    for (int i = threadIdx.x; i < 9 * HC; i += 256) {
+        const int ci = i / 9, tap = i - ci * 9;
+        sw[tap * HC + ci] = w[i];
+    }
+    __syncthreads();
+    const int64_t N = (int64_t)B * H * W;
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+        const int b = (int)(n / ((int64_t)H * W));
+        const int r = (int)(n - (int64_t)b * H * W), h = r / W, ww = r - h * W;
+        float acc[HC];
+#pragma unroll
+        for (int c = 0; c < HC; ++c) acc[c] = 0.f;
+        // output q = (qh,qw) with tap (kh,kw) reads padded position (qh+kh, qw+kw) = pixel reflect(qh+kh-1), reflect(qw+kw-1)
+        for (int qh = h - 2; qh <= h + 2; ++qh) {
+            if (qh < 0 || qh >= H) continue;
+            for (int qw = ww - 2; qw <= ww + 2; ++qw) {
+                if (qw < 0 || qw >= W) continue;
+                const float g = dz[((int64_t)b * H + qh) * W + qw];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    if (reflect1(qh + kh - 1, H) != h) continue;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        if (reflect1(qw + kw - 1, W) != ww) continue;
+                        const float* wt = &sw[(kh * 3 + kw) * HC];
+#pragma unroll
+                        for (int c = 0; c < HC; ++c) acc[c] = fmaf(g, wt[c], acc[c]);
+                    }
+                }
+            }
+        }
+        f4v* o = (f4v*)(dx + n * HC);
+#pragma unroll
+        for (int q = 0; q < HC / 4; ++q) o[q] = (f4v){acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
+    }
+}
+
+// d/dw, d/dbias: per-workgroup partial sums of dz[p] * x[src(p,tap), ci] (145 values), fixed-order second stage
+__global__ __launch_bounds__(256) void k_head_bwd_weight(const float* __restrict__ dz, const float* __restrict__ x, float* __restrict__ partials,
+                                                         int B, int H, int W) {
+    const int64_t N = (int64_t)B * H * W;
+    // thread t accumulates column t of the 145-vector (144 weights + bias) over this workgroup's pixel range; all threads
+    // walk the same pixels, so dz[n] is a broadcast read and the x reads of a wave stay inside 9 neighbouring pixels.
+    const int col = threadIdx.x;
+    const int tap = col / HC, ci = col - tap * HC, kh = tap / 3, kw = tap - kh * 3;
+    float s = 0.f;
+    const int64_t per = (N + gridDim.x - 1) / gridDim.x;
+    const int64_t n0 = (int64_t)blockIdx.x * per, n1 = (n0 + per < N) ? n0 + per : N;
+    if (col < 9 * HC + 1 && n0 < n1) {
+        int b = (int)(n0 / ((int64_t)H * W));
+        const int r0 = (int)(n0 - (int64_t)b * H * W);
+        int h = r0 / W, ww = r0 - h * W;                       // advanced incrementally: no divisions in the pixel loop
+        for (int64_t n = n0; n < n1; ++n) {
+            const float g = dz[n];
+            if (col == 9 * HC) s += g;
+            else {
+                const int ys = reflect1(h + kh - 1, H), xs = reflect1(ww + kw - 1, W);
+                s = fmaf(g, x[(((int64_t)b * H + ys) * W + xs) * HC + ci], s);
+            }
+            if (++ww == W) { ww = 0; if (++h == H) { h = 0; ++b; } }
+        }
+    }
+    if (col < 9 * HC + 1) partials[(int64_t)blockIdx.x * (9 * HC + 1) + col] = s;
+}
+
+__global__ __launch_bounds__(256) void k_head_wreduce(const float* __restrict__ partials, int nparts, float* __restrict__ dw, float* __restrict__ dbias) {
+    const int col = threadIdx.x;
+    if (col >= 9 * HC + 1) return;
+    float s = 0.f;
+    for (int i = 0; i < nparts; ++i) s += partials[(int64_t)i * (9 * HC + 1) + col];
+    if (col == 9 * HC) { if (dbias) dbias[0] = s; }
+    else { const int tap = col / HC, ci = col - tap * HC; dw[ci * 9 + tap] = s; }       // (1,16,3,3)
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------------
 static inline int egrid(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
@@ -686,6 +799,27 @@ int e2e_conv2d_act_bwd(const float* dy, const float* y, const float* scale, floa
     E2E_REQUIRE(dy && y && dz && n > 0 && C > 0 && act >= 0 && act <= 3, E2E_ERR_ARG, "e2e_conv2d_act_bwd: bad argument");
     hipLaunchKernelGGL(k_act_bwd, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, scale, dz, n, C, act);
     E2E_LAUNCH_CHECK("e2e_conv2d_act_bwd");
+    return E2E_OK;
+}
+
+#define HEAD_PARTS 4096
+int e2e_head_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int act, void* stream) {
+    E2E_REQUIRE(x && w && y && B > 0 && H >= 2 && W >= 2 && Cin == HC, E2E_ERR_ARG, "e2e_head_fwd: bad argument (the head takes %d channels)", HC);
+    hipLaunchKernelGGL(k_head_fwd, dim3(egrid((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, H, W, act);
+    E2E_LAUNCH_CHECK("e2e_head_fwd");
+    return E2E_OK;
+}
+int64_t e2e_head_workspace_floats(void) { return (int64_t)HEAD_PARTS * (9 * HC + 1); }
+int e2e_head_bwd(const float* dz, const float* x, const float* w, float* dx, float* dw, float* dbias, float* workspace, int B, int H,
+                 int W, int Cin, void* stream) {
+    E2E_REQUIRE(dz && x && w && workspace && B > 0 && H >= 2 && W >= 2 && Cin == HC, E2E_ERR_ARG, "e2e_head_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) hipLaunchKernelGGL(k_head_bwd_data, dim3(egrid((int64_t)B * H * W)), dim3(256), 0, st, dz, w, dx, B, H, W);
+    if (dw) {
+        hipLaunchKernelGGL(k_head_bwd_weight, dim3(HEAD_PARTS), dim3(256), 0, st, dz, x, workspace, B, H, W);
+        hipLaunchKernelGGL(k_head_wreduce, dim3(1), dim3(256), 0, st, workspace, HEAD_PARTS, dw, dbias);
+    }
+    E2E_LAUNCH_CHECK("e2e_head_bwd");
     return E2E_OK;
 }
 

@@ -73,12 +73,16 @@ SIGNATURES = {
     "e2e_conv2d_gather_adjoint": [c_fp] + [c_int] * 7 + [c_fp, c_fp, c_int, c_int, c_fp],
     "e2e_conv2d_wgrad_workspace_floats": [c_int] * 8,
     "e2e_conv2d_bwd_weight": [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp] + [c_int] * 13 + [c_f32, c_f32, c_fp],
+    "e2e_head_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp],
+    "e2e_head_workspace_floats": [],
+    "e2e_head_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp],
 }
 _RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats": c_i64,
             "e2e_warp_photo_lossgrad_workspace_floats": c_i64, "e2e_pf_workspace_bytes": c_i64,
             "e2e_knn1_workspace_bytes": c_i64, "e2e_median_workspace_bytes": c_i64,
             "e2e_depth_scale_workspace_bytes": c_i64, "e2e_reduce_workspace_floats": c_i64,
-            "e2e_conv2d_wgrad_workspace_floats": c_i64, "e2e_conv2d_splitk_workspace_floats": c_i64}
+            "e2e_conv2d_wgrad_workspace_floats": c_i64, "e2e_conv2d_splitk_workspace_floats": c_i64,
+            "e2e_head_workspace_floats": c_i64}
 
 _lib = None
 

@@ -9,6 +9,26 @@ from . import _lib as L
 ACT = {None: 0, "relu": 1, "elu": 2, "disp": 3}
 CL = torch.channels_last
 
+# k-major GEMM copies of the weights, cached until the weights change.  A weight tensor changes either through torch
+# (its _version counter moves) or through FusedAdam's raw-pointer kernel, which bumps WEIGHT_EPOCH.
+WEIGHT_EPOCH = [0]
+_LAYOUTS = {}
+
+
+def _weight_layouts(w, want_bwd):
+    Cout, Cin, KH, KW = w.shape
+    key = (w.data_ptr(), w._version, WEIGHT_EPOCH[0])
+    hit = _LAYOUTS.get(id(w))
+    if hit is not None and hit[0] == key and (hit[2] is not None or not want_bwd):
+        return hit[1], hit[2]
+    ldf, ldb = _ld(Cout), _ld(Cin)
+    mk = lambda rows, ld, exact: (torch.empty if exact else torch.zeros)(rows, ld, device=w.device, dtype=torch.float32)
+    wf = mk(KH * KW * Cin, ldf, ldf == Cout)
+    wb = mk(KH * KW * Cout, ldb, ldb == Cin) if want_bwd else None
+    L.call("e2e_conv_weight_layouts", L.ptr(w), Cout, Cin, KH, KW, L.ptr(wf), ldf, L.ptr(wb), ldb, L.stream())
+    _LAYOUTS[id(w)] = (key, wf, wb)
+    return wf, wb
+
 
 def available():
     try:
@@ -18,8 +38,42 @@ def available():
 
 
 def supports(weight):
-    """Layer shapes the MFMA path covers: Cout a multiple of 16 (the 1-channel disparity head is the exception)."""
-    return weight.shape[0] % 16 == 0
+    """Layer shapes the native kernels cover: Cout a multiple of 16 (MFMA path) or the 16 -> 1 3x3 disparity head."""
+    return weight.shape[0] % 16 == 0 or tuple(weight.shape) == (1, 16, 3, 3)
+
+
+class _Head(torch.autograd.Function):
+    """Conv3x3(reflect) 16 -> 1 + activation: 144-tap dot product per pixel (HBM-bound VALU kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x = _cl(L.dev(x, "input"))
+        B, C, H, W = x.shape
+        w = L.dev(weight, "weight").contiguous()
+        y = torch.empty(B, 1, H, W, device=x.device, dtype=torch.float32)
+        L.call("e2e_head_fwd", L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), B, H, W, C, act, L.stream())
+        ctx.save_for_backward(x, w, y)
+        ctx.cfg = (act, bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        act, has_bias = ctx.cfg
+        B, C, H, W = x.shape
+        st = L.stream()
+        g = g.contiguous()
+        dz = g
+        if act:
+            dz = torch.empty_like(g)
+            L.call("e2e_conv2d_act_bwd", L.ptr(g), L.ptr(y), None, L.ptr(dz), g.numel(), 1, act, st)
+        dx = torch.empty(B, C, H, W, device=g.device, dtype=torch.float32, memory_format=CL) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        db = torch.empty(1, device=g.device, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
+        ws = torch.empty(L.load().e2e_head_workspace_floats(), device=g.device, dtype=torch.float32)
+        L.call("e2e_head_bwd", L.ptr(dz), L.ptr(x), L.ptr(w), L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws), B, H, W, C, st)
+        return dx, dw, db, None
 
 
 def _cl(t):
@@ -45,14 +99,12 @@ class _Conv2d(torch.autograd.Function):
             raise ValueError(f"input has {C1} channels, the convolution expects {Cin}")
         Ho, Wo = (Hs + 2 * pad - KH) // stride + 1, (Ws + 2 * pad - KW) // stride + 1
         dev = src0.device
-        w = L.dev(weight, "weight").contiguous()
+        w = L.dev(weight, "weight")
+        if not w.is_contiguous():
+            raise ValueError("convolution weights must be contiguous (Cout,Cin,KH,KW)")
         need_bwd_w = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         ldf, ldb = _ld(Cout), _ld(Cin)
-        wf = torch.zeros(KH * KW * Cin, ldf, device=dev, dtype=torch.float32) if ldf != Cout else torch.empty(KH * KW * Cin, ldf, device=dev, dtype=torch.float32)
-        wb = None
-        if need_bwd_w:
-            wb = torch.zeros(KH * KW * Cout, ldb, device=dev, dtype=torch.float32) if ldb != Cin else torch.empty(KH * KW * Cout, ldb, device=dev, dtype=torch.float32)
-        L.call("e2e_conv_weight_layouts", L.ptr(w), Cout, Cin, KH, KW, L.ptr(wf), ldf, L.ptr(wb), ldb, L.stream())
+        wf, wb = _weight_layouts(w, need_bwd_w)
         # epilogue vectors: y = scale * conv + shift ; a plain bias is shift with unit scale
         sh = shift
         if bias is not None:
@@ -126,6 +178,11 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, pad_mode="zeros", act=None
     bn_scale_shift: (scale, shift) per output channel (folded eval-mode BatchNorm; constants, no gradient)."""
     if pad_mode not in ("zeros", "reflect"):
         raise ValueError(f"pad_mode {pad_mode}")
+    if weight.shape[0] == 1:
+        if tuple(weight.shape) != (1, 16, 3, 3) or pad_mode != "reflect" or padding != 1 or stride != 1 or skip is not None \
+                or upsample != 1 or residual is not None or bn_scale_shift is not None:
+            raise NotImplementedError("single-output-channel convolution other than the 16->1 reflect 3x3 disparity head")
+        return _Head.apply(x, weight, bias, ACT[act])
     scale, shift = bn_scale_shift if bn_scale_shift is not None else (None, None)
     if bias is not None and bn_scale_shift is not None:
         raise ValueError("a bias together with a folded BatchNorm is not used by the network")

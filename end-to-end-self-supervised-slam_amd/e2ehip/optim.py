@@ -26,6 +26,8 @@ class FlatParams:
             for p, o in zip(params, offs):
                 self.data[o:o + p.numel()].copy_(p.reshape(-1))
                 p.data = self.data[o:o + p.numel()].view_as(p)
+        from . import conv
+        conv.WEIGHT_EPOCH[0] += 1                      # parameters moved: cached GEMM layouts are stale
         self.bind_grads()
 
     def bind_grads(self):
@@ -77,5 +79,7 @@ class FusedAdam(torch.optim.Optimizer):
             self._build()
         g = self.param_groups[0]
         self.steps += 1
+        from . import conv
+        conv.WEIGHT_EPOCH[0] += 1                      # the kernel rewrites the weights behind torch's version counters
         L.call("e2e_adam_step", L.ptr(self.flat.data), L.ptr(self.flat.grad), L.ptr(self.m), L.ptr(self.v), self.flat.numel,
                float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self.steps, L.stream())

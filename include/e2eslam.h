@@ -309,6 +309,16 @@ int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1,
                           int Cout, int Ho, int Wo, int KH, int KW, int stride, int pad,
                           int pad_mode, int accumulate, float in_sub, float in_mul, void* stream);
 
+/* The 1-channel disparity head: Conv3x3(reflect) 16 -> 1 (+ activation), networks.py:271-272,289-290.
+ * x (B,H,W,16) NHWC, w (1,16,3,3), y (B,H,W).  Backward: dz = dY*act' (e2e_conv2d_act_bwd) ->
+ * dx (B,H,W,16), dw (1,16,3,3), dbias (1); any of dx / dw may be NULL.
+ * workspace: e2e_head_workspace_floats() floats. */
+int e2e_head_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
+                 int Cin, int act, void* stream);
+int64_t e2e_head_workspace_floats(void);
+int e2e_head_bwd(const float* dz, const float* x, const float* w, float* dx, float* dw, float* dbias,
+                 float* workspace, int B, int H, int W, int Cin, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,3 +85,21 @@ def test_conv_forward_backward(case):
     for t, a, b in zip(diff, grads, grads_r):
         e = ((a.double() - b).abs().max() / (b.abs().max() + 1e-30)).item()
         assert e < 5e-5, f"grad of tensor {tuple(t.shape)}: {e:.2e}"
+
+
+@pytest.mark.parametrize("H,W,act", [(20, 28, "disp"), (5, 7, None), (64, 96, "disp")])
+def test_disparity_head(H, W, act):
+    """Conv3x3(reflect) 16 -> 1 (+ 10*sigmoid+0.01): dedicated kernels, forward and all three gradients."""
+    from e2ehip import conv
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(2, 16, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(1, 16, 3, 3, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    b = torch.randn(1, generator=g).to(DEV).requires_grad_(True)
+    y = conv.conv2d(x, w, b, 1, 1, "reflect", act)
+    yr = F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="reflect"), w.double(), b.double())
+    if act == "disp":
+        yr = 10 * torch.sigmoid(yr) + 0.01
+    assert ((y.double() - yr).abs().max() / yr.abs().max()).item() < 2e-5
+    gy = torch.randn(y.shape, generator=g).to(DEV)
+    for a, r in zip(torch.autograd.grad(y, [x, w, b], gy), torch.autograd.grad(yr, [x, w, b], gy.double())):
+        assert ((a.double() - r).abs().max() / (r.abs().max() + 1e-30)).item() < 5e-5
