@@ -663,13 +663,18 @@ __global__ __launch_bounds__(256) void k_head_bwd_weight(const float* __restrict
     if (col < 9 * HC + 1) partials[(int64_t)blockIdx.x * (9 * HC + 1) + col] = s;
 }
 
+// one workgroup per column of the 145-vector: 256 threads add the per-workgroup partials (fixed assignment, fixed
+// combine order => deterministic)
 __global__ __launch_bounds__(256) void k_head_wreduce(const float* __restrict__ partials, int nparts, float* __restrict__ dw, float* __restrict__ dbias) {
-    const int col = threadIdx.x;
-    if (col >= 9 * HC + 1) return;
+    __shared__ float red[4];
+    const int col = blockIdx.x;
     float s = 0.f;
-    for (int i = 0; i < nparts; ++i) s += partials[(int64_t)i * (9 * HC + 1) + col];
-    if (col == 9 * HC) { if (dbias) dbias[0] = s; }
-    else { const int tap = col / HC, ci = col - tap * HC; dw[ci * 9 + tap] = s; }       // (1,16,3,3)
+    for (int i = threadIdx.x; i < nparts; i += 256) s += partials[(int64_t)i * (9 * HC + 1) + col];
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        if (col == 9 * HC) { if (dbias) dbias[0] = t; }
+        else { const int tap = col / HC, ci = col - tap * HC; dw[ci * 9 + tap] = t; }       // (1,16,3,3)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -802,7 +807,7 @@ int e2e_conv2d_act_bwd(const float* dy, const float* y, const float* scale, floa
     return E2E_OK;
 }
 
-#define HEAD_PARTS 4096
+#define HEAD_PARTS 2048
 int e2e_head_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int act, void* stream) {
     E2E_REQUIRE(x && w && y && B > 0 && H >= 2 && W >= 2 && Cin == HC, E2E_ERR_ARG, "e2e_head_fwd: bad argument (the head takes %d channels)", HC);
     hipLaunchKernelGGL(k_head_fwd, dim3(egrid((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, H, W, act);
@@ -817,7 +822,7 @@ int e2e_head_bwd(const float* dz, const float* x, const float* w, float* dx, flo
     if (dx) hipLaunchKernelGGL(k_head_bwd_data, dim3(egrid((int64_t)B * H * W)), dim3(256), 0, st, dz, w, dx, B, H, W);
     if (dw) {
         hipLaunchKernelGGL(k_head_bwd_weight, dim3(HEAD_PARTS), dim3(256), 0, st, dz, x, workspace, B, H, W);
-        hipLaunchKernelGGL(k_head_wreduce, dim3(1), dim3(256), 0, st, workspace, HEAD_PARTS, dw, dbias);
+        hipLaunchKernelGGL(k_head_wreduce, dim3(9 * HC + 1), dim3(256), 0, st, workspace, HEAD_PARTS, dw, dbias);
     }
     E2E_LAUNCH_CHECK("e2e_head_bwd");
     return E2E_OK;

@@ -12,13 +12,14 @@ CL = torch.channels_last
 # k-major GEMM copies of the weights, cached until the weights change.  A weight tensor changes either through torch
 # (its _version counter moves) or through FusedAdam's raw-pointer kernel, which bumps WEIGHT_EPOCH.
 WEIGHT_EPOCH = [0]
-_LAYOUTS = {}
 
 
 def _weight_layouts(w, want_bwd):
+    """The cache entry lives ON the weight tensor object (a recycled allocation of another tensor can therefore never
+    alias it); it is valid while (data_ptr, torch version counter, FusedAdam epoch) are unchanged."""
     Cout, Cin, KH, KW = w.shape
     key = (w.data_ptr(), w._version, WEIGHT_EPOCH[0])
-    hit = _LAYOUTS.get(id(w))
+    hit = getattr(w, "_e2e_layouts", None)
     if hit is not None and hit[0] == key and (hit[2] is not None or not want_bwd):
         return hit[1], hit[2]
     ldf, ldb = _ld(Cout), _ld(Cin)
@@ -26,7 +27,10 @@ def _weight_layouts(w, want_bwd):
     wf = mk(KH * KW * Cin, ldf, ldf == Cout)
     wb = mk(KH * KW * Cout, ldb, ldb == Cin) if want_bwd else None
     L.call("e2e_conv_weight_layouts", L.ptr(w), Cout, Cin, KH, KW, L.ptr(wf), ldf, L.ptr(wb), ldb, L.stream())
-    _LAYOUTS[id(w)] = (key, wf, wb)
+    try:
+        w._e2e_layouts = (key, wf, wb)
+    except AttributeError:
+        pass
     return wf, wb
 
 
@@ -86,7 +90,7 @@ def _ld(n):
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src0, src1, weight, bias, scale, shift, residual, up, stride, pad, pad_mode, act, in_norm):
+    def forward(ctx, src0, src1, weight, bias, scale, shift, residual, up, stride, pad, pad_mode, act, in_norm, wf, wb):
         Cout, Cin, KH, KW = weight.shape
         src0 = _cl(L.dev(src0, "input"))
         B, C1 = src0.shape[0], src0.shape[1]
@@ -102,9 +106,9 @@ class _Conv2d(torch.autograd.Function):
         w = L.dev(weight, "weight")
         if not w.is_contiguous():
             raise ValueError("convolution weights must be contiguous (Cout,Cin,KH,KW)")
-        need_bwd_w = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         ldf, ldb = _ld(Cout), _ld(Cin)
-        wf, wb = _weight_layouts(w, need_bwd_w)
+        if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and wb is None:
+            wb = _weight_layouts(w, True)[1]
         # epilogue vectors: y = scale * conv + shift ; a plain bias is shift with unit scale
         sh = shift
         if bias is not None:
@@ -169,7 +173,7 @@ class _Conv2d(torch.autograd.Function):
                              device=dev, dtype=torch.float32)
             L.call("e2e_conv2d_bwd_weight", L.ptr(dZ), L.ptr(src0), L.ptr(src1), C1, up, L.ptr(gw), L.ptr(gb), L.ptr(ws), B, Hs, Ws, Cin,
                    Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, 0, isub, imul, st)
-        return g0, g1, gw, gb, None, None, d_res, None, None, None, None, None, None
+        return g0, g1, gw, gb, None, None, d_res, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, pad_mode="zeros", act=None, bn_scale_shift=None, residual=None,
@@ -186,5 +190,9 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, pad_mode="zeros", act=None
     scale, shift = bn_scale_shift if bn_scale_shift is not None else (None, None)
     if bias is not None and bn_scale_shift is not None:
         raise ValueError("a bias together with a folded BatchNorm is not used by the network")
+    if not weight.is_contiguous():
+        raise ValueError("convolution weights must be contiguous (Cout,Cin,KH,KW)")
+    want_bwd = torch.is_grad_enabled() and (x.requires_grad or (skip is not None and skip.requires_grad))
+    wf, wb = _weight_layouts(weight, want_bwd)          # cached on the Parameter object across forwards
     return _Conv2d.apply(x, skip, weight, bias, scale, shift, residual, int(upsample), int(stride), int(padding),
-                         1 if pad_mode == "reflect" else 0, ACT[act], in_norm)
+                         1 if pad_mode == "reflect" else 0, ACT[act], in_norm, wf, wb)
