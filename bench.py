@@ -24,6 +24,10 @@ for p in (ROOT, os.path.join(ROOT, "end-to-end-self-supervised-slam_amd"), os.pa
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, KiB -> bytes;
+# profiles/r01_final_summaries.md).  The kernel loads 4- and 12-byte items, a pattern for which gfx950's FETCH_SIZE
+# halving (seen on 16-B/lane streams) is not calibrated, so the counters are taken at face value.
+TRAFFIC_NOTE = {(False, 1): (11088 + 2475) * 1024}
 
 
 def cpu_baseline(H, W, budget_s=12.0):
@@ -124,6 +128,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--workload", default="warp", choices=["warp", "full"],
                     help="warp: BASELINE configs[1] (default). full: whole refinement step incl. depth network, 3-D loss, Adam, map update")
+    ap.add_argument("--device-geometry", action="store_true", help="derive the geometry in the kernel from device K/inv_K/T (default: host kernel arguments)")
     ap.add_argument("--split", action="store_true", help="two-kernel form (e2e_warp_photo_fwd + _bwd) instead of the single-launch lossgrad")
     a = ap.parse_args()
 
@@ -151,6 +156,9 @@ def main():
     src, tgt = t["src"].permute(0, 3, 1, 2), t["tgt"].permute(0, 3, 1, 2)     # NHWC memory, NCHW view
     plan = (WarpPhotoPlan(B, H, W, dev, "border", True, "l2") if a.split else LossGradPlan(B, H, W, dev, "border", True, "l2", 1.0, 1e-2)).bind(
         t["depth"], dsrc.to(dev), (s["depth"] + 0.05).to(dev), (dsrc + 0.05).to(dev), src, tgt, t["K"], t["invK"], t["T"])
+    if not a.split and B == 1 and not a.device_geometry:
+        # poses / intrinsics are dataset inputs the host already holds: the pair's 12 geometry numbers go in as kernel arguments
+        plan.set_host_geometry(s["K"][0], s["invK"][0], s["T"][0])
 
     def step():
         if a.split:
@@ -212,10 +220,12 @@ def main():
             launch_ms = {"warp_photo_fwd+reduce": fwd_ms, "warp_photo_bwd": bwd_ms}
             alg = {"fwd": fwd_bytes, "bwd": bwd_bytes}
         else:
-            dom_ms = kernel_ms(plan.step)
+            # the dominant kernel ALONE (k_warp_photo_lossgrad, no second-stage reduce), one HIP event pair per launch
+            dom_ms = kernel_ms(lambda: plan.step(want_loss=False))
+            both_ms = kernel_ms(plan.step)
             # single launch: reads depth 4N + src 12N + tgt 12N + reg (init_t, init_s, depth_s) 12N; writes g_tgt 4N + g_src 4N
-            dom, dom_bytes = "e2e_warp_photo_lossgrad(+reduce)", 48 * N
-            launch_ms = {"warp_photo_lossgrad+reduce": dom_ms}
+            dom, dom_bytes = "k_warp_photo_lossgrad", 48 * N
+            launch_ms = {"k_warp_photo_lossgrad": dom_ms, "lossgrad+reduce (both launches of a step)": both_ms}
             alg = {"lossgrad": dom_bytes, "survey_8d_fused_minimum_equiv": (92 + 24) * N}
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     if rank == 0:
@@ -225,9 +235,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic 640x480 RGB-D pair, warp+photometric(+l2 depth-reg) fwd+bwd kernels only",
                        "pairs_per_launch": B, "height": H, "width": W, "launch": "eager" if graph is None else "hipGraph replay",
-                       "kernels_per_step": 3 if a.split else 2},
+                       "kernels_per_step": 3 if a.split else 2,
+                       "geometry": "device matrices" if (a.split or B != 1 or a.device_geometry) else "host kernel arguments"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_NOTE.get((a.split, B), None),
                          "launch_ms": launch_ms, "algorithmic_bytes": alg},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -45,6 +45,8 @@ SIGNATURES = {
     "e2e_warp_photo_lossgrad_workspace_floats": [c_int, c_int, c_int],
     "e2e_warp_photo_lossgrad": [c_fp, c_fp, Strides, c_fp, Strides, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp,
                                 c_f32, c_f32, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "e2e_warp_photo_lossgrad_hostgeo": [c_fp, c_fp, Strides, c_fp, Strides, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_f32, c_f32,
+                                        c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp],
     "e2e_vertex_normal_maps": [c_fp, c_fp, c_fp, c_f32, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
     "e2e_vertex_maps_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
     "e2e_transform_points": [c_fp, c_fp, c_fp, c_i64, c_int, c_fp],

@@ -4,6 +4,8 @@
 step is exactly: e2e_warp_photo_fwd (+ its 1-block reduction) and e2e_warp_photo_bwd -- no
 allocator traffic, no host synchronisation.  The build's driver and bench.py use it; the autograd
 form for ad-hoc use is ops.warp_photometric."""
+import ctypes
+
 import torch
 
 from . import _lib as L
@@ -70,11 +72,33 @@ class LossGradPlan(WarpPhotoPlan):
         # zero-initialised ONCE: the tail of the workspace is the arrival ticket, which the kernel re-arms itself
         self.ws = torch.zeros(L.load().e2e_warp_photo_lossgrad_workspace_floats(B, H, W), device=device, dtype=torch.float32)
 
-    def step(self):
-        """-> (loss[2], g_depth_tgt, g_depth_src); gradients are of w_photo*loss[0] + w_reg*loss[1]."""
+    def set_host_geometry(self, K, inv_K, T):
+        """Give the pair's geometry as HOST (CPU) 4x4 tensors: the 12 numbers of c = d * M [x,y,1] + p4 then travel as
+        kernel arguments (B = 1).  Call again whenever the pair changes; None switches back to the device matrices."""
+        if K is None:
+            self._geo = None
+            return self
+        if self.B != 1:
+            raise ValueError("host geometry is per keyframe pair (B = 1)")
+        K, inv_K, T = (t.detach().double().cpu().reshape(4, 4) for t in (K, inv_K, T))
+        P = (K @ T)[:3]
+        M = P[:, :3] @ inv_K[:3, :3]
+        self._geo = (ctypes.c_float * 12)(*[float(v) for v in M.reshape(-1)], *[float(v) for v in P[:, 3]])
+        return self
+
+    def step(self, want_loss=True):
+        """-> (loss[2], g_depth_tgt, g_depth_src); gradients are of w_photo*loss[0] + w_reg*loss[1].
+        want_loss=False launches the main kernel only (no second-stage reduction of the loss)."""
         dt, ds, it, is_, src, tgt, K, iK, T = self.t
+        loss_ptr = L.ptr(self.loss) if want_loss else None
+        if getattr(self, "_geo", None) is not None:
+            L.call("e2e_warp_photo_lossgrad_hostgeo", L.ptr(dt), L.ptr(src), L.strides4(src), L.ptr(tgt), L.strides4(tgt),
+                   ctypes.cast(self._geo, ctypes.c_void_p), self.use_mask, self.pad, self.reg, L.ptr(it) if self.reg else None,
+                   L.ptr(is_) if self.reg else None, L.ptr(ds) if self.reg else None, self.w_photo, self.w_reg, loss_ptr,
+                   L.ptr(self.g_depth_tgt), L.ptr(self.g_depth_src) if self.reg else None, L.ptr(self.ws), self.H, self.W, L.stream())
+            return self.loss, self.g_depth_tgt, self.g_depth_src
         L.call("e2e_warp_photo_lossgrad", L.ptr(dt), L.ptr(src), L.strides4(src), L.ptr(tgt), L.strides4(tgt), L.ptr(K), L.ptr(iK),
                L.ptr(T), self.use_mask, self.pad, self.reg, L.ptr(it) if self.reg else None, L.ptr(is_) if self.reg else None,
-               L.ptr(ds) if self.reg else None, self.w_photo, self.w_reg, L.ptr(self.loss), L.ptr(self.g_depth_tgt),
+               L.ptr(ds) if self.reg else None, self.w_photo, self.w_reg, loss_ptr, L.ptr(self.g_depth_tgt),
                L.ptr(self.g_depth_src) if self.reg else None, L.ptr(self.ws), self.B, self.H, self.W, L.stream())
         return self.loss, self.g_depth_tgt, self.g_depth_src

@@ -61,6 +61,7 @@ class SLAM:
             # tensor contract stands in (colours already in [0,1], i.e. after the reference's `colors /= 255`).
             self._sequence = make_sequence(self.sequence_length, a.DATA.height, a.DATA.width, seed=int(getattr(a.DATA, "seed", 1234)),
                                            holes=0.1 if a.DATA.name == "TUM" else 0.0)
+        self._K_host = self._sequence[2][0, 0].detach().cpu().clone()
         self.colors, self.gt_depths, self.intrinsics, self.poses = (t.to(self.device).contiguous() for t in self._sequence)
         _, L, self.H, self.W, _ = self.colors.shape
         self.sequence_length = min(self.sequence_length, L)
@@ -157,6 +158,8 @@ class SLAM:
             d_src, d_tgt = depth[0:1], depth[1:2]
             self.plan.bind(d_tgt.detach(), d_src.detach(), initial[1:2] if use_reg else None, initial[0:1] if use_reg else None,
                            src, tgt, K, inv_K, T)
+            if refine_step == 0:                     # the pair's geometry is host data: pass it as kernel arguments
+                self.plan.set_host_geometry(self._K_host, torch.pinverse(self._K_host), transform[0, 1].cpu())
             loss2, g_tgt, g_src = self.plan.step()
             g_depth = torch.cat([g_src if use_reg else torch.zeros_like(g_tgt), g_tgt], 0)
             roots, grads = [depth], [g_depth]

@@ -140,7 +140,8 @@ int e2e_warp_photo_bwd(const float* depth_tgt, const float* src, e2e_strides src
  *   loss_out[0] = photometric mean, loss_out[1] = regulariser (unweighted);
  *   g_depth_tgt = d(w_photo*loss0 + w_reg*loss1)/d(depth_tgt), g_depth_src likewise (reg_kind != 0).
  * workspace: e2e_warp_photo_lossgrad_workspace_floats floats (per-workgroup partial sums; a
- * 2-wave second-stage kernel adds them in a fixed order => bitwise reproducible loss). */
+ * second-stage kernel adds them in a fixed order => bitwise reproducible loss).  loss_out == NULL
+ * skips that second launch (gradients only). */
 int64_t e2e_warp_photo_lossgrad_workspace_floats(int B, int H, int W);
 int e2e_warp_photo_lossgrad(const float* depth_tgt, const float* src, e2e_strides src_strides,
                             const float* tgt, e2e_strides tgt_strides, const float* K,
@@ -149,6 +150,18 @@ int e2e_warp_photo_lossgrad(const float* depth_tgt, const float* src, e2e_stride
                             const float* depth_src, float w_photo, float w_reg, float* loss_out,
                             float* g_depth_tgt, float* g_depth_src, float* workspace, int B, int H,
                             int W, void* stream);
+
+/* Same launch for ONE keyframe pair (B = 1) when the caller already holds the pair's geometry on the HOST (poses are
+ * dataset inputs): geometry12_host = rows of M = (K T)[:3,:3] inv(K)[:3,:3] (9 floats) followed by p4 = (K T)[:3,3]
+ * (3 floats), so that c = d * M [x,y,1]^T + p4.  The 12 numbers travel as kernel arguments: no device round trip and no
+ * workgroup barrier before the first loads. */
+int e2e_warp_photo_lossgrad_hostgeo(const float* depth_tgt, const float* src, e2e_strides src_strides,
+                                    const float* tgt, e2e_strides tgt_strides,
+                                    const float* geometry12_host, int use_mask, int padding_mode,
+                                    int reg_kind, const float* reg_init_tgt, const float* reg_init_src,
+                                    const float* depth_src, float w_photo, float w_reg, float* loss_out,
+                                    float* g_depth_tgt, float* g_depth_src, float* workspace, int H,
+                                    int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* RGB-D unprojection and the PointFusion map step -- gradslam (un-vendored dependency; semantics */

@@ -236,3 +236,26 @@ def test_lossgrad_single_launch_vs_oracle(H, W, B, pad, reg, nhwc):
         _grad_close(gds, dsc.grad, what="g depth_src")
     l2, g2, _ = plan.step()
     assert torch.equal(l2, loss) and torch.equal(g2, gdt)       # bitwise reproducible
+
+
+def test_lossgrad_host_geometry_matches_device_geometry():
+    """The 12 geometry numbers as kernel arguments (computed on the host in fp64) vs derived in the kernel from K, inv_K, T."""
+    from e2ehip.fused import LossGradPlan
+    H, W = 96, 128
+    s = make_pair(H, W, seed=5)
+    gen = torch.Generator().manual_seed(5)
+    dsrc = s["depth"] + 0.1 * torch.rand(s["depth"].shape, generator=gen)
+    args = (s["depth"].to(DEV), dsrc.to(DEV), (s["depth"] + 0.05).to(DEV), (dsrc + 0.05).to(DEV), s["src"].to(DEV).permute(0, 3, 1, 2),
+            s["tgt"].to(DEV).permute(0, 3, 1, 2), s["K"].to(DEV), s["invK"].to(DEV), s["T"].to(DEV))
+    a = LossGradPlan(1, H, W, torch.device(DEV), "border", True, "l2", 1.0, 1e-2).bind(*args)
+    la, ga, gsa = (t.clone() for t in a.step())
+    b = LossGradPlan(1, H, W, torch.device(DEV), "border", True, "l2", 1.0, 1e-2).bind(*args).set_host_geometry(s["K"][0], s["invK"][0], s["T"][0])
+    lb, gb, gsb = b.step()
+    torch.testing.assert_close(lb, la, rtol=1e-5, atol=1e-8)
+    dc = s["depth"].clone().requires_grad_(True)
+    synth, valid, grid = warp_loss.inverse_warp(dc, s["src"].permute(0, 3, 1, 2), s["K"], s["invK"], s["T"], "border")
+    lp, _ = warp_loss.masked_photometric_mean(synth, s["tgt"].permute(0, 3, 1, 2), valid)
+    (lp + 1e-2 * (warp_loss.depth_regularizer(s["depth"] + 0.05, dc, "l2"))).backward()
+    _close(lb[0], lp, what="photometric")
+    _gdepth_close(gb, dc.grad, grid, what="g depth_tgt (host geometry)")
+    assert torch.equal(gsb, gsa)
