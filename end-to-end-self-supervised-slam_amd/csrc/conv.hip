@@ -82,9 +82,9 @@ __device__ __forceinline__ bool tap_coord(const ConvArgs& a, int yd, int xd, int
     }
 }
 
-template <int WM, int WN, int TN, int VEC, bool TRANSPOSED>
+template <int WM, int WN, int TM, int TN, int VEC, bool TRANSPOSED>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
-    constexpr int BM = 32 * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
+    constexpr int BM = 32 * WM * TM, BN = 32 * TN * WN, NT = 64 * WM * WN;
     constexpr int KQ = CBK / VEC;                          // k-groups (of VEC) per chunk
     constexpr int A_PER = (KQ + NT / BM - 1) / (NT / BM);  // vector loads of A per thread per chunk (guarded)
     constexpr int B_CNT = CBK * (BN / 4);                  // float4 loads of the B tile
@@ -208,29 +208,34 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         }
     };
 
-    f16v acc[TN];
+    f16v acc[TM][TN];       // TM x TN accumulators of 32x32 per wave: operand fragments are reused TN resp. TM times
 #pragma unroll
-    for (int t = 0; t < TN; ++t)
+    for (int u = 0; u < TM; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][t][r] = 0.f;
 
     if (cbeg < cend) {
         load_chunk(cbeg);
         store_chunk(0);
     }
     __syncthreads();
-    const int arow_l = wm * 32 + (lane & 31), khalf = lane >> 5;
+    const int arow_l = wm * TM * 32 + (lane & 31), khalf = lane >> 5;
     for (int c = cbeg; c < cend; ++c) {
         const int buf = (c - cbeg) & 1;
         if (c + 1 < cend) load_chunk(c + 1);                // global loads in flight under the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < CBK / 2; ++kk) {
-            const float av = As[buf][kk * 2 + khalf][arow_l];
+            float av[TM], bv[TN];
 #pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                const float bv = Bs[buf][kk * 2 + khalf][(wn * TN + t) * 32 + (lane & 31)];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-            }
+            for (int u = 0; u < TM; ++u) av[u] = As[buf][kk * 2 + khalf][arow_l + u * 32];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) bv[t] = Bs[buf][kk * 2 + khalf][(wn * TN + t) * 32 + (lane & 31)];
+#pragma unroll
+            for (int u = 0; u < TM; ++u)
+#pragma unroll
+                for (int t = 0; t < TN; ++t) acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[t], acc[u][t], 0, 0, 0);
         }
         if (c + 1 < cend) store_chunk(buf ^ 1);
         __syncthreads();
@@ -239,32 +244,36 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     if (a.ksplit > 1) {                                      // raw partial sums; the epilogue runs after the reduction
         float* slab = a.slab + (int64_t)blockIdx.z * Ntot * a.Ncols;
 #pragma unroll
-        for (int t = 0; t < TN; ++t) {
-            const int col = c0 + (wn * TN + t) * 32 + (lane & 31);
-            if (col >= a.Ncols) continue;
+        for (int u = 0; u < TM; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t n = n0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (n < Ntot) slab[n * a.Ncols + col] = acc[t][r];
+            for (int t = 0; t < TN; ++t) {
+                const int col = c0 + (wn * TN + t) * 32 + (lane & 31);
+                if (col >= a.Ncols) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t n = n0 + (wm * TM + u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    if (n < Ntot) slab[n * a.Ncols + col] = acc[u][t][r];
+                }
             }
-        }
         return;
     }
     // ---- epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5) ----------------------------
 #pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        const int col = c0 + (wn * TN + t) * 32 + (lane & 31);
-        if (col >= a.Ncols) continue;
-        const float sc = a.scale ? a.scale[col] : 1.f, sh = a.shift ? a.shift[col] : 0.f;
+    for (int u = 0; u < TM; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t n = n0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            if (n >= Ntot) continue;
-            float v = fmaf(acc[t][r], sc, sh);
-            if (a.res) v += a.res[n * a.Ncols + col];
-            a.out[n * a.Ncols + col] = apply_act(v, a.act);
+        for (int t = 0; t < TN; ++t) {
+            const int col = c0 + (wn * TN + t) * 32 + (lane & 31);
+            if (col >= a.Ncols) continue;
+            const float sc = a.scale ? a.scale[col] : 1.f, sh = a.shift ? a.shift[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t n = n0 + (wm * TM + u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (n >= Ntot) continue;
+                float v = fmaf(acc[u][t][r], sc, sh);
+                if (a.res) v += a.res[n * a.Ncols + col];
+                a.out[n * a.Ncols + col] = apply_act(v, a.act);
+            }
         }
-    }
 }
 
 __global__ __launch_bounds__(256) void k_conv_splitk_epilogue(const float* __restrict__ slab, int S, int64_t total, int Ncols,
@@ -706,30 +715,34 @@ static void launch_gemm(ConvArgs a, int vec, float* workspace, hipStream_t st) {
         const int Sz = (nchunks + a.cps - 1) / a.cps;
         a.ksplit = Sz;
         dim3 g((unsigned)((Ntot + 63) / 64), (unsigned)((a.Ncols + 63) / 64), (unsigned)Sz);
-        hipLaunchKernelGGL((k_conv_gemm<2, 2, 1, 4, TR>), g, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_conv_gemm<2, 2, 1, 1, 4, TR>), g, dim3(256), 0, st, a);
         const int64_t total = Ntot * a.Ncols;
         hipLaunchKernelGGL(k_conv_splitk_epilogue, dim3(egrid(total)), dim3(256), 0, st, workspace, Sz, total, a.Ncols, a.scale, a.shift, a.res, a.out, a.act);
         return;
     }
     if (vec == 1) {
         dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 63) / 64));
-        hipLaunchKernelGGL((k_conv_gemm<4, 1, 2, 1, TR>), g, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_conv_gemm<4, 1, 1, 2, 1, TR>), g, dim3(256), 0, st, a);
         return;
     }
-    // tile choice: enough workgroups for 256 CUs.  128x64 for large pixel counts, 64x64 for medium, 32x128 for the deep, small-spatial layers
-    const int64_t wg_big = ((Ntot + 127) / 128) * ((a.Ncols + 63) / 64);
+    // tile choice (rows x cols): big tiles reuse each operand fragment twice (half the LDS / L2 traffic per MFMA) but need
+    // enough workgroups to fill 256 CUs; thin layers (Cout <= 32) use 128x32.
+    auto wgs = [&](int bm, int bn) { return ((Ntot + bm - 1) / bm) * ((a.Ncols + bn - 1) / bn); };
     if (a.Ncols <= 32) {
         dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 31) / 32));
-        hipLaunchKernelGGL((k_conv_gemm<4, 1, 1, 4, TR>), g, dim3(256), 0, st, a);
-    } else if (wg_big >= 512) {
+        hipLaunchKernelGGL((k_conv_gemm<4, 1, 1, 1, 4, TR>), g, dim3(256), 0, st, a);
+    } else if (a.Ncols >= 128 && wgs(128, 128) >= 512) {
+        dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 127) / 128));
+        hipLaunchKernelGGL((k_conv_gemm<2, 2, 2, 2, 4, TR>), g, dim3(256), 0, st, a);          // 128 x 128
+    } else if (wgs(128, 64) >= 512) {
         dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 63) / 64));
-        hipLaunchKernelGGL((k_conv_gemm<4, 1, 2, 4, TR>), g, dim3(256), 0, st, a);
-    } else if (((Ntot + 63) / 64) * ((a.Ncols + 63) / 64) >= 256 || a.Ncols < 128) {
+        hipLaunchKernelGGL((k_conv_gemm<2, 2, 2, 1, 4, TR>), g, dim3(256), 0, st, a);          // 128 x 64
+    } else if (wgs(64, 64) >= 256 || a.Ncols < 128) {
         dim3 g((unsigned)((Ntot + 63) / 64), (unsigned)((a.Ncols + 63) / 64));
-        hipLaunchKernelGGL((k_conv_gemm<2, 2, 1, 4, TR>), g, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_conv_gemm<2, 2, 1, 1, 4, TR>), g, dim3(256), 0, st, a);          // 64 x 64
     } else {
         dim3 g((unsigned)((Ntot + 31) / 32), (unsigned)((a.Ncols + 127) / 128));
-        hipLaunchKernelGGL((k_conv_gemm<1, 4, 1, 4, TR>), g, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_conv_gemm<1, 4, 1, 1, 4, TR>), g, dim3(256), 0, st, a);          // 32 x 128
     }
 }
 

@@ -57,10 +57,18 @@ class SLAM:
         if self._sequence is None:
             if a.DATA.name not in ("ICL", "TUM", "synthetic"):
                 raise ValueError("Dataset Not Found")
-            # ICL / TUM file loaders are the next scope row; a synthetic sequence with the same
-            # tensor contract stands in (colours already in [0,1], i.e. after the reference's `colors /= 255`).
-            self._sequence = make_sequence(self.sequence_length, a.DATA.height, a.DATA.width, seed=int(getattr(a.DATA, "seed", 1234)),
-                                           holes=0.1 if a.DATA.name == "TUM" else 0.0)
+            root = os.path.join(str(getattr(a.DATA, "data_path", "") or ""), a.DATA.name)
+            if a.DATA.name in ("ICL", "TUM") and os.path.isdir(root):
+                # the reference's loader call (online_adaption.py:69-84); the first item is the whole sequence (:212)
+                from gradslam.datasets import ICL, TUM
+                ds = (ICL if a.DATA.name == "ICL" else TUM)(basedir=root, seqlen=self.sequence_length, height=a.DATA.height, width=a.DATA.width,
+                                                            dilation=a.DATA.dilation, stride=a.DATA.stride, start=a.DATA.start)
+                colors, depths, K, poses = ds[0][:4]
+                self._sequence = (colors[None] / 255.0, depths[None], K[None], poses[None])            # `colors /= 255.0` (:215)
+            else:
+                # no dataset on this machine: a synthetic sequence with the same tensor contract (colours already in [0,1])
+                self._sequence = make_sequence(self.sequence_length, a.DATA.height, a.DATA.width, seed=int(getattr(a.DATA, "seed", 1234)),
+                                               holes=0.1 if a.DATA.name == "TUM" else 0.0)
         self._K_host = self._sequence[2][0, 0].detach().cpu().clone()
         self.colors, self.gt_depths, self.intrinsics, self.poses = (t.to(self.device).contiguous() for t in self._sequence)
         _, L, self.H, self.W, _ = self.colors.shape
