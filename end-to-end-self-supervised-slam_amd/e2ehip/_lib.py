@@ -78,13 +78,15 @@ SIGNATURES = {
     "e2e_head_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp],
     "e2e_head_workspace_floats": [],
     "e2e_head_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp],
+    "e2e_icp_workspace_bytes": [],
+    "e2e_icp_normal_equations": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f32, c_i64, c_fp, c_fp, c_fp],
 }
 _RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats": c_i64,
             "e2e_warp_photo_lossgrad_workspace_floats": c_i64, "e2e_pf_workspace_bytes": c_i64,
             "e2e_knn1_workspace_bytes": c_i64, "e2e_median_workspace_bytes": c_i64,
             "e2e_depth_scale_workspace_bytes": c_i64, "e2e_reduce_workspace_floats": c_i64,
             "e2e_conv2d_wgrad_workspace_floats": c_i64, "e2e_conv2d_splitk_workspace_floats": c_i64,
-            "e2e_head_workspace_floats": c_i64}
+            "e2e_head_workspace_floats": c_i64, "e2e_icp_workspace_bytes": c_i64}
 
 _lib = None
 

@@ -8,7 +8,7 @@ from ..structures import Pointclouds, RGBDImages
 
 class ICPSLAM(nn.Module):
     """Point-based SLAM with plain aggregation as the map update (gradslam ICPSLAM).
-    odom: "gt" uses the frame's own poses.  "icp" / "gradicp" are the next scope row."""
+    odom: "gt" uses the frame's own poses; "icp" / "gradicp" run frame-to-model point-to-plane ICP (e2ehip.icp)."""
 
     def __init__(self, *, odom="gradicp", dsratio=4, numiters=20, damp=1e-8, dist_thresh=None, lambda_max=2.0, B=1.0, B2=1.0,
                  nu=200.0, device=None):
@@ -16,6 +16,7 @@ class ICPSLAM(nn.Module):
         if odom not in ("gt", "icp", "gradicp"):
             raise ValueError(f"odometry method ({odom}) not supported for PointFusion. Currently supported odometry modules for PointFusion are: 'gt', 'icp', 'gradicp'")
         self.odom, self.dsratio, self.numiters = odom, dsratio, numiters
+        self.damp, self.dist_thresh, self.lambda_max, self.B, self.B2, self.nu = damp, dist_thresh, lambda_max, B, B2, nu
         self.device = torch.device(device) if device is not None else torch.device("cpu")
 
     # -- odometry ------------------------------------------------------------------------------------
@@ -34,8 +35,31 @@ class ICPSLAM(nn.Module):
             if not live_frame.has_poses:
                 raise ValueError("`live_frame` must have poses when `prev_frame` is None or `odom='gt'`")
             return live_frame.poses
-        raise NotImplementedError(f"odom='{self.odom}' (ICP / GradICP frame-to-model odometry) is not built yet: SURVEY.md 8f row N1. "
-                                  "Use MODEL.odom: gt (dataset poses), which is what the map-step parity is defined on.")
+        # frame-to-model ICP against the active map points, initialised with the previous frame's pose
+        from e2ehip import icp
+        if len(pointclouds) != 1 or live_frame.shape[0] != 1:
+            raise NotImplementedError("batch size 1 only (OPTIMIZATION.batch_size, configs/config.yaml:60)")
+        if not pointclouds.has_points:
+            raise ValueError("frame-to-model odometry needs a non-empty map")
+        fm = self._resident_map(pointclouds, live_frame)
+        pose, self.last_trace = icp.frame_to_model(fm, live_frame.depth_image[0, 0, ..., 0].detach(), live_frame.intrinsics[0, 0],
+                                                   prev_frame.poses[0, 0], dsratio=self.dsratio, numiters=self.numiters, damp=self.damp,
+                                                   dist_thresh=self.dist_thresh, mode=self.odom, lambda_max=self.lambda_max, B=self.B,
+                                                   B2=self.B2, nu=self.nu)
+        return pose.view(1, 1, 4, 4)
+
+    def _resident_map(self, pointclouds, live_frame):
+        from e2ehip.fusionmap import FusionMap
+        fm = pointclouds._fusion_maps
+        if fm is None:
+            _, _, H, W = live_frame.shape
+            M = pointclouds.points_list[0].shape[0]
+            fm = FusionMap(max(getattr(self, "map_capacity", None) or 0, M + 64 * H * W), H, W, live_frame.device,
+                           getattr(self, "dist_th", 0.05), getattr(self, "angle_th", 20), getattr(self, "sigma", 0.6))
+            fm.load_state(pointclouds.points_list[0].detach(), pointclouds.normals_list[0].detach(), pointclouds.colors_list[0].detach(),
+                          pointclouds.features_list[0].detach().reshape(-1))
+            pointclouds._fusion_maps = fm
+        return fm
 
     # -- map update ------------------------------------------------------------------------------------
     def _map(self, pointclouds, live_frame, inplace=False):

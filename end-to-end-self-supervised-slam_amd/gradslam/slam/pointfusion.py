@@ -54,13 +54,7 @@ class PointFusion(ICPSLAM):
             # graph of the depth (the 3-D loss differentiates through this: online_adaption.py:461-469,638-645)
             out = frame_as_pointcloud(live_frame)
             return out
-        fm = pointclouds._fusion_maps
-        if fm is None:              # adopt an externally built cloud: copy it into a resident map once
-            M = pointclouds.points_list[0].shape[0]
-            cap = self.map_capacity or max(64 * H * W, M + H * W)
-            fm = FusionMap(cap, H, W, live_frame.device, self.dist_th, self.angle_th, self.sigma)
-            fm.load_state(pointclouds.points_list[0].detach(), pointclouds.normals_list[0].detach(), pointclouds.colors_list[0].detach(),
-                          pointclouds.features_list[0].detach().reshape(-1))
+        fm = self._resident_map(pointclouds, live_frame)      # adopts an externally built cloud once
         fm.step(live_frame.rgb_image[0, 0].detach(), live_frame.depth_image[0, 0, ..., 0].detach(),
                 live_frame.intrinsics[0, 0], live_frame.poses[0, 0])
         P, Nn, C, cc = fm.live()

@@ -79,8 +79,9 @@ class SLAM:
         self.models = {}
         if a.MODEL.slam != "PointFusion":
             raise NotImplementedError("MODEL.slam: only PointFusion is on the online-adaption path")
-        if a.MODEL.odom != "gt":
-            raise NotImplementedError("MODEL.odom: ICP / GradICP odometry is the next scope row (SURVEY.md 8f N1); use gt")
+        if a.MODEL.odom not in ("gt", "icp", "gradicp"):
+            raise ValueError("MODEL.odom must be gt, icp or gradicp")
+        self.estimated_poses = []          # (frame index, estimated pose, ground-truth pose) when odometry runs
         if a.MODEL.depth_network != "indoor":
             raise ValueError("Given {} is not a valid depth network option".format(a.MODEL.depth_network))
         self.models["depth"] = DispResNet_Indoor(num_layers=a.MODEL.num_layers, pretrained=a.MODEL.weights_init_encoder == "imagenet")
@@ -215,8 +216,23 @@ class SLAM:
         K = self.intrinsics[0, 0]
         if self.first_iter:
             self.map.step(colors[0, 0], depth[0, 0], K, poses[0, 0])
-        self.map.step(colors[0, 1], depth[1, 0], K, poses[0, 1])
+        live_pose = poses[0, 1]
+        if self.args.MODEL.odom != "gt":
+            # the reference passes prev_frame here (online_adaption.py:362-363): frame-to-model odometry from the
+            # previous keyframe's pose; the map is fused with the ESTIMATED pose and the pose itself is dropped there --
+            # we keep it to report the trajectory error
+            from e2ehip import icp
+            live_pose, _ = icp.frame_to_model(self.map, depth[1, 0], K, poses[0, 0], numiters=self.args.MODEL.numiters, mode=self.args.MODEL.odom)
+            self.estimated_poses.append((live_pose, poses[0, 1]))
+        self.map.step(colors[0, 1], depth[1, 0], K, live_pose)
         return self.map
+
+    def absolute_trajectory_error(self):
+        """RMSE of the camera-centre error of the odometry estimates against the dataset poses (metres)."""
+        if not self.estimated_poses:
+            return 0.0
+        e = torch.stack([(p[:3, 3] - g[:3, 3]).norm() for p, g in self.estimated_poses])
+        return float(torch.sqrt((e ** 2).mean()))
 
 
 def default_config(height=480, width=640, sequence_length=60):

@@ -332,6 +332,20 @@ int64_t e2e_head_workspace_floats(void);
 int e2e_head_bwd(const float* dz, const float* x, const float* w, float* dx, float* dw, float* dbias,
                  float* workspace, int B, int H, int W, int Cin, void* stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Frame-to-model ICP odometry (gradslam odometry providers; MODEL.odom: icp | gradicp)          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* One Gauss-Newton reduction of point-to-plane ICP: for every source point s_i (n,3) with nearest
+ * target t_i = tgt[idx[i]] and normal n_i: A_i = [n_i, s_i x n_i], b_i = n_i . (t_i - s_i).
+ * out29 (device, float64) = upper triangle of A^T A (21, row-major), A^T b (6), inlier count,
+ * sum b_i^2.  Points with dists[i] >= dist_thresh^2 are skipped (dist_thresh < 0: keep all).
+ * workspace: e2e_icp_workspace_bytes() bytes. */
+int64_t e2e_icp_workspace_bytes(void);
+int e2e_icp_normal_equations(const float* src, const float* tgt, const float* tgt_normals,
+                             const long long* idx, const float* dists, float dist_thresh, int64_t n,
+                             double* out29, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,8 +88,9 @@ def test_gradslam_surface_pointfusion_and_knn_loss():
     assert ((dpred.grad.cpu() - dc.grad).abs().max() / dc.grad.abs().max()) < 1e-3
     with pytest.raises(ValueError):
         knn_points_loss(torch.zeros(2, 4, 3, device=DEV), torch.zeros(1, 4, 3, device=DEV))
-    with pytest.raises(NotImplementedError):
-        PointFusion(odom="gradicp", device=DEV).step(cloud, rgbd(c1, d1, p1), rgbd(c0, d0, p0))
+    # the reference's default odometry (configs/config.yaml:30): frame-to-model GradICP from the previous frame's pose
+    c2, est = PointFusion(odom="gradicp", device=DEV).step(cloud, rgbd(c1, d1, None), rgbd(c0, d0, p0))
+    assert tuple(est.shape) == (1, 1, 4, 4) and torch.isfinite(est).all() and c2.points_list[0].shape[0] >= cloud.points_list[0].shape[0]
 
 
 def test_image_recover_slam_and_icpslam():
