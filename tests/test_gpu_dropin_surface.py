@@ -58,7 +58,8 @@ def test_gradslam_surface_pointfusion_and_knn_loss():
     slam = PointFusion(odom="gt", dist_th=0.05, angle_th=20, sigma=0.6, device=DEV)
 
     def rgbd(c, d, p):
-        return RGBDImages(c.to(DEV)[None, None], d.to(DEV)[None, None, ..., None], K.to(DEV)[None, None], p.to(DEV)[None, None])
+        return RGBDImages(c.to(DEV)[None, None], d.to(DEV)[None, None, ..., None], K.to(DEV)[None, None],
+                          None if p is None else p.to(DEV)[None, None])
 
     cloud = Pointclouds(device=DEV)
     cloud, _ = slam.step(cloud, rgbd(c0, d0, p0), None)
