@@ -216,72 +216,88 @@ __global__ __launch_bounds__(LNT) void k_warp_photo_lossgrad(
     const float gup = w_photo * kmean * (0.85f / 3.f);      // upstream gradient on every ssim_c(q)
     float lsum = 0.f;
     {
-        // thread -> one column of the 34-wide statistics region and a strip of RPS consecutive rows: the RPS+2 window
-        // rows are read from LDS once per channel and their horizontal sums are shared by the strip's q's (measured:
-        // the former one-q-per-iteration loop spent 8.2 k of a workgroup's 18.5 k cycles here, mostly LDS latency).
-        constexpr int NSTRIP = LNT / LG_W;                         // 7
-        constexpr int RPS = (LG_H + NSTRIP - 1) / NSTRIP;          // 3 (PPT 2) / 2 (PPT 1)
-        const int lx = tid % LG_W, strip = tid / LG_W;
-        const int ly0 = strip * RPS;
-        const int qx = tx0 + lx - 1;
-        const bool col_ok = strip < NSTRIP && qx >= 0 && qx < W;
-        float sacc[RPS], lacc[RPS];
+        // thread -> one column of the 34-wide statistics region and a strip of RPS consecutive rows.  The RPS+2 window
+        // rows are read from LDS once per channel and their horizontal sums shared by the strip's q's; the q's are then
+        // processed in vertical PAIRS so that the whole SSIM / gradient formula runs on v_pk_*_f32 (the kernel is
+        // VALU-issue bound: profiles/r01_warp_photo_lossgrad_history.md).  Threads past the last strip skip the phase.
+        constexpr int RPS = 2 * PPT;                               // 4 (PPT 2) / 2 (PPT 1)
+        constexpr int NSTRIP = (LG_H + RPS - 1) / RPS;             // 5
+        constexpr int NUNIT = 3 * NSTRIP * LG_W;                   // (channel, strip, column) units: 510 -> 2 per thread
+        constexpr int UPT = (NUNIT + LNT - 1) / LNT;
+        f2 lacc = (f2){0.f, 0.f};
+#pragma unroll 1
+        for (int uu = 0; uu < UPT; ++uu) {
+            const int unit = tid + uu * LNT;
+            if (unit >= NUNIT) break;
+            const int c = unit / (NSTRIP * LG_W), rem = unit - c * (NSTRIP * LG_W);
+            const int strip = rem / LG_W, lx = rem - strip * LG_W;
+            const int ly0 = strip * RPS;
+            const int qx = tx0 + lx - 1;
+            const bool col_ok = qx >= 0 && qx < W;
+            const bool own_col = lx >= 1 && lx <= LT_W;
+            {
+                f2 hs1[RPS + 2], hs2[RPS + 2];
+                float hxy[RPS + 2], adf[RPS + 2];
 #pragma unroll
-        for (int j = 0; j < RPS; ++j) { sacc[j] = 0.f; lacc[j] = 0.f; }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            f2 hs1[RPS + 2], hs2[RPS + 2], ctr[RPS + 2];
-            float hxy[RPS + 2];
-#pragma unroll
-            for (int r = 0; r < RPS + 2; ++r) {
-                const int row = min(ly0 + r, LX_H - 1);            // rows past the region are never combined into a valid q
-                const f2* w = &sxy[c][row * LX_W + lx];
-                const f2 e0 = w[0], e1 = w[1], e2 = w[2];
-                hs1[r] = e0 + e1 + e2;
-                hs2[r] = e0 * e0 + e1 * e1 + e2 * e2;
-                hxy[r] = fmaf(e0.x, e0.y, fmaf(e1.x, e1.y, e2.x * e2.y));
-                ctr[r] = e1;
-            }
-#pragma unroll
-            for (int j = 0; j < RPS; ++j) {
-                const int ly = ly0 + j;
-                const int qy = ty0 + ly - 1;
-                const bool in = col_ok && ly < LG_H && qy >= 0 && qy < H;
-                float G1 = 0.f, G2 = 0.f, G3 = 0.f;
-                if (in) {
-                    const f2 s1 = hs1[j] + hs1[j + 1] + hs1[j + 2], s2 = hs2[j] + hs2[j + 1] + hs2[j + 2];
-                    const float sxy_ = hxy[j] + hxy[j + 1] + hxy[j + 2];
-                    const float k9 = 1.f / 9.f;
-                    const float mux = s1.x * k9, muy = s1.y * k9;
-                    const float sxx = s2.x * k9, syy = s2.y * k9, sxyv = sxy_ * k9;
-                    const float sigx = sxx - mux * mux, sigy = syy - muy * muy, sigxy = sxyv - mux * muy;
-                    const float A1 = fmaf(2.f * mux, muy, 1e-4f), A2 = fmaf(2.f, sigxy, 9e-4f);
-                    const float B1 = fmaf(mux, mux, fmaf(muy, muy, 1e-4f)), B2 = sigx + sigy + 9e-4f;
-                    const float inv = __builtin_amdgcn_rcpf(B1 * B2);
-                    const float S = A1 * A2 * inv;
-                    const float t = 0.5f - 0.5f * S;                 // (1 - S)/2
-                    const bool act = t >= 0.f && t <= 1.f;
-                    const bool own = ly >= 1 && ly <= LT_H && lx >= 1 && lx <= LT_W;
-                    if (own) {
-                        sacc[j] += fminf(fmaxf(t, 0.f), 1.f);
-                        lacc[j] += fabsf(ctr[j + 1].y - ctr[j + 1].x);
-                    }
-                    const float gS = act ? -0.5f * gup : 0.f;
-                    // dS/dmu_x = 2 mu_y (A2 - A1)/(B1 B2) - 2 S mu_x (1/B1 - 1/B2) ; 1/B1 = B2*inv, 1/B2 = B1*inv
-                    G1 = gS * (2.f * muy * (A2 - A1) * inv - 2.f * S * mux * (B2 - B1) * inv);
-                    G2 = gS * (-S * B1 * inv);
-                    G3 = gS * (2.f * A1 * inv);
+                for (int r = 0; r < RPS + 2; ++r) {
+                    const int row = min(ly0 + r, LX_H - 1);        // rows past the region are never combined into a valid q
+                    const f2* w = &sxy[c][row * LX_W + lx];
+                    const f2 e0 = w[0], e1 = w[1], e2 = w[2];
+                    hs1[r] = e0 + e1 + e2;
+                    hs2[r] = e0 * e0 + e1 * e1 + e2 * e2;
+                    hxy[r] = fmaf(e0.x, e0.y, fmaf(e1.x, e1.y, e2.x * e2.y));
+                    adf[r] = fabsf(e1.y - e1.x);
                 }
-                if (strip < NSTRIP && ly < LG_H) {
-                    const int i = ly * LG_W + lx;
-                    sg[c * 3 + 0][i] = G1;
-                    sg[c * 3 + 1][i] = G2;
-                    sg[c * 3 + 2][i] = G3;
+#pragma unroll
+                for (int jp = 0; jp < RPS; jp += 2) {              // q rows (ly0+jp, ly0+jp+1) in the two halves of every f2
+                    const int lya = ly0 + jp, lyb = lya + 1;
+                    const int qya = ty0 + lya - 1, qyb = qya + 1;
+                    const bool in_a = col_ok && lya < LG_H && qya >= 0 && qya < H;
+                    const bool in_b = col_ok && lyb < LG_H && qyb >= 0 && qyb < H;
+                    const f2 m1 = hs1[jp + 1] + hs1[jp + 2], m2 = hs2[jp + 1] + hs2[jp + 2];
+                    const float mxy = hxy[jp + 1] + hxy[jp + 2];
+                    const f2 s1a = m1 + hs1[jp], s1b = m1 + hs1[jp + 3];
+                    const f2 s2a = m2 + hs2[jp], s2b = m2 + hs2[jp + 3];
+                    const f2 k9 = (f2){1.f / 9.f, 1.f / 9.f};
+                    const f2 MX = (f2){s1a.x, s1b.x} * k9, MY = (f2){s1a.y, s1b.y} * k9;
+                    const f2 EXX = (f2){s2a.x, s2b.x} * k9, EYY = (f2){s2a.y, s2b.y} * k9;
+                    const f2 EXY = (f2){mxy + hxy[jp], mxy + hxy[jp + 3]} * k9;
+                    const f2 MXX = MX * MX, MYY = MY * MY, MXY = MX * MY;
+                    const f2 SIGX = EXX - MXX, SIGY = EYY - MYY, SIGXY = EXY - MXY;
+                    const f2 c1 = (f2){1e-4f, 1e-4f}, c2 = (f2){9e-4f, 9e-4f}, two = (f2){2.f, 2.f};
+                    const f2 A1 = two * MXY + c1, A2 = two * SIGXY + c2;
+                    const f2 B1 = MXX + MYY + c1, B2 = SIGX + SIGY + c2;
+                    const f2 D = B1 * B2;
+                    const f2 INV = (f2){__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y)};
+                    const f2 S = A1 * A2 * INV;
+                    const f2 TT = (f2){0.5f, 0.5f} - (f2){0.5f, 0.5f} * S;          // (1 - S)/2
+                    const bool act_a = TT.x >= 0.f && TT.x <= 1.f, act_b = TT.y >= 0.f && TT.y <= 1.f;
+                    const bool own_a = in_a && own_col && lya >= 1 && lya <= LT_H;
+                    const bool own_b = in_b && own_col && lyb >= 1 && lyb <= LT_H;
+                    const f2 lv = (f2){0.85f / 3.f, 0.85f / 3.f} * (f2){fminf(fmaxf(TT.x, 0.f), 1.f), fminf(fmaxf(TT.y, 0.f), 1.f)} +
+                                  (f2){0.15f / 3.f, 0.15f / 3.f} * (f2){adf[jp + 1], adf[jp + 2]};
+                    lacc += (f2){own_a ? lv.x : 0.f, own_b ? lv.y : 0.f};
+                    // dS/dmu_x = 2 mu_y (A2 - A1)/(B1 B2) - 2 S mu_x (1/B1 - 1/B2) ; 1/B1 = B2*inv, 1/B2 = B1*inv
+                    const f2 GI = (f2){act_a ? -0.5f * gup : 0.f, act_b ? -0.5f * gup : 0.f} * INV;
+                    const f2 G1 = two * GI * (MY * (A2 - A1) - S * MX * (B2 - B1));
+                    const f2 G2 = -(GI * S) * B1;
+                    const f2 G3 = two * GI * A1;
+                    if (lya < LG_H) {
+                        const int i = lya * LG_W + lx;
+                        sg[c * 3 + 0][i] = in_a ? G1.x : 0.f;
+                        sg[c * 3 + 1][i] = in_a ? G2.x : 0.f;
+                        sg[c * 3 + 2][i] = in_a ? G3.x : 0.f;
+                    }
+                    if (lyb < LG_H) {
+                        const int i = lyb * LG_W + lx;
+                        sg[c * 3 + 0][i] = in_b ? G1.y : 0.f;
+                        sg[c * 3 + 1][i] = in_b ? G2.y : 0.f;
+                        sg[c * 3 + 2][i] = in_b ? G3.y : 0.f;
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < RPS; ++j) lsum += 0.85f * (sacc[j] * (1.f / 3.f)) + 0.15f * (lacc[j] * (1.f / 3.f));
+        lsum = lacc.x + lacc.y;
     }
     __syncthreads();
 
