@@ -4,7 +4,11 @@ sys.path[:0] = [os.path.join(ROOT, "end-to-end-self-supervised-slam_amd")]
 from e2ehip import nn_ops
 DEV = "cuda:0"
 cases = {"up01": (16, 0, 2, 480, 640, 16, 3, 1, 1, "reflect", "elu"), "layer1": (64, 0, 1, 120, 160, 64, 3, 1, 1, "zeros", "relu"),
-         "up11": (32, 64, 2, 240, 320, 32, 3, 1, 1, "reflect", "elu"), "l2s2": (64, 0, 1, 120, 160, 128, 3, 2, 1, "zeros", "relu")}
+         "up11": (32, 64, 2, 240, 320, 32, 3, 1, 1, "reflect", "elu"), "l2s2": (64, 0, 1, 120, 160, 128, 3, 2, 1, "zeros", "relu"),
+         "conv1": (3, 0, 1, 480, 640, 64, 7, 2, 3, "zeros", "relu"), "layer2": (128, 0, 1, 60, 80, 128, 3, 1, 1, "zeros", "relu"),
+         "layer3": (256, 0, 1, 30, 40, 256, 3, 1, 1, "zeros", "relu"), "layer4": (512, 0, 1, 15, 20, 512, 3, 1, 1, "zeros", "relu"),
+         "up41": (256, 256, 2, 30, 40, 256, 3, 1, 1, "reflect", "elu"), "up00": (32, 0, 1, 240, 320, 16, 3, 1, 1, "reflect", "elu"),
+         "up21": (64, 64, 2, 120, 160, 64, 3, 1, 1, "reflect", "elu")}
 Cx, Cs, up, H, W, Cout, k, s, p, pm, act = cases[sys.argv[1]]
 B = 2
 x = torch.randn(B, Cx, H // up, W // up, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
