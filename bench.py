@@ -119,8 +119,8 @@ def full_step_bench(a, rank, world, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 2000 for --workload warp, 30 for full)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 200 / 6)")
     ap.add_argument("--batch", type=int, default=1, help="keyframe pairs per launch (reference: 1)")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
@@ -131,6 +131,10 @@ def main():
     ap.add_argument("--device-geometry", action="store_true", help="derive the geometry in the kernel from device K/inv_K/T (default: host kernel arguments)")
     ap.add_argument("--split", action="store_true", help="two-kernel form (e2e_warp_photo_fwd + _bwd) instead of the single-launch lossgrad")
     a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 2000 if a.workload == "warp" else 30
+    if a.warmup is None:
+        a.warmup = 200 if a.workload == "warp" else 6
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

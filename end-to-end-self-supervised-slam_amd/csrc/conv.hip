@@ -46,6 +46,7 @@ struct ConvArgs {
     // k_conv_splitk_epilogue adds the slices in order and applies the epilogue.  ksplit == 1: direct epilogue.
     int ksplit, cps;
     float* slab;
+    int64_t bytes0, bytes1, bytesw;   // extents of src0 / src1 / w for the buffer resources (< 2 GB each)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -82,121 +83,156 @@ __device__ __forceinline__ bool tap_coord(const ConvArgs& a, int yd, int xd, int
     }
 }
 
-template <int WM, int WN, int TM, int TN, int VEC, bool TRANSPOSED>
+// Thread -> A element mapping.  VEC == 4 (every layer but conv1): consecutive lanes fetch consecutive 16-byte channel
+// quads of ONE gathered pixel, so a wave-level load touches 64*16/(4*CB) rows x (4*CB contiguous bytes) -- full 128-byte
+// lines at CB = 32.  (The first version gave each lane its own row: 64 different lines per instruction, and the kernel
+// ran at the L1 request rate, not the MFMA rate: time did not react to chunk depth, read scheduling or warp
+// specialisation -- profiles/r01_notes.md.)  The LDS tile stays k-major for conflict-free MFMA operand reads; its row
+// stride is padded so that the transposing stores of 4*CB/16 lanes per row spread over banks.
+template <int WM, int WN, int TM, int TN, int VEC, bool TRANSPOSED, int CB>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     constexpr int BM = 32 * WM * TM, BN = 32 * TN * WN, NT = 64 * WM * WN;
-    constexpr int KQ = CBK / VEC;                          // k-groups (of VEC) per chunk
-    constexpr int A_PER = (KQ + NT / BM - 1) / (NT / BM);  // vector loads of A per thread per chunk (guarded)
-    constexpr int B_CNT = CBK * (BN / 4);                  // float4 loads of the B tile
+    constexpr int KQ = CB / VEC;                           // k-groups (of VEC) per chunk
+    constexpr int A_CNT = BM * KQ;                         // (row, k-group) elements of the A tile
+    constexpr int A_PER = (A_CNT + NT - 1) / NT;
+    constexpr int B_CNT = CB * (BN / 4);                   // float4 loads of the B tile
     constexpr int B_PER = (B_CNT + NT - 1) / NT;
-    static_assert(NT % BM == 0, "tile / thread-count mismatch");
-    __shared__ float As[2][CBK][BM];
-    __shared__ float Bs[2][CBK][BN];
+    constexpr int APAD = (VEC == 4) ? 1 : 0;
+    static_assert(NT % KQ == 0 && NT % BM == 0, "tile / thread-count mismatch");
+    __shared__ float As[2][CB][BM + APAD];
+    __shared__ float Bs[2][CB][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int64_t Ntot = (int64_t)a.B * a.Hd * a.Wd;
     const int64_t n0 = (int64_t)blockIdx.x * BM;
     const int c0 = blockIdx.y * BN;
     const int K = a.KH * a.KW * a.Cin;
-    const int nchunks_all = (K + CBK - 1) / CBK;
+    const int nchunks_all = (K + CB - 1) / CB;
     const int cbeg = (a.ksplit > 1) ? blockIdx.z * a.cps : 0;
     const int cend = (a.ksplit > 1) ? min(nchunks_all, cbeg + a.cps) : nchunks_all;
 
-    // ---- per-thread A row (fixed for the whole K loop) --------------------------------------------------------------
-    const int arow = tid % BM;
-    const int64_t an = n0 + arow;
-    const bool arow_ok = an < Ntot;
-    int ab = 0, ayd = 0, axd = 0;
-    if (arow_ok) {
-        ab = (int)(an / ((int64_t)a.Hd * a.Wd));
-        const int r = (int)(an - (int64_t)ab * a.Hd * a.Wd);
-        ayd = r / a.Wd;
-        axd = r - ayd * a.Wd;
+    // ---- per-thread A slots: slot j is element tid + j*NT of the tile -----------------------------------------------
+    //   VEC == 4: element e -> row e / KQ, k-quad e % KQ (the quad is the same for all slots since NT % KQ == 0)
+    //   VEC == 1: element e -> row e % BM, k e / BM      (conv1: 3 channels, lanes walk along the image row)
+    int arow[A_PER], ab[A_PER], ayd[A_PER], axd[A_PER];
+    bool arow_ok[A_PER];
+    const int akq = (VEC == 4) ? tid % KQ : tid / BM;
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) {
+        const int e = tid + j * NT;
+        arow[j] = (VEC == 4) ? e / KQ : e % BM;
+        const int64_t an = n0 + arow[j];
+        arow_ok[j] = e < A_CNT && an < Ntot;
+        ab[j] = ayd[j] = axd[j] = 0;
+        if (arow_ok[j]) {
+            const int hw = a.Hd * a.Wd;
+            ab[j] = (int)(an / hw);
+            const int r = (int)(an - (int64_t)ab[j] * hw);
+            ayd[j] = r / a.Wd;
+            axd[j] = r - ayd[j] * a.Wd;
+        }
     }
-    const int akq0 = tid / BM;                              // this thread's first k-quad inside a chunk
-    const int Hl = a.Hs / a.up, Wl = a.Ws / a.up, C2 = a.Cin - a.C1;
+    const int sh = a.up >> 1;                                // up is 1 or 2: source coordinate = full-res coordinate >> sh
+    const int Hl = a.Hs >> sh, Wl = a.Ws >> sh, C2 = a.Cin - a.C1;
 
     f4v areg[A_PER];
     float areg1[A_PER];
     f4v breg[B_PER];
 
-    // VEC == 4: the K loop is walked tap-major.  The gather coordinates of this thread's row change only when the
-    // tap changes (every Cin/16 chunks), so the div/mod decode, reflection and pointer selection are hoisted out of
-    // the chunk loop: per chunk the address is (tap pointer) + channel offset.
-    const int cpt = (VEC == 4) ? a.Cin / CBK : 1;          // chunks per tap
-    int ld_tap = -1, ld_cc = 0;                              // state of the LOAD stream (runs one chunk ahead)
-    const float* tp0 = nullptr;
-    const float* tp1 = nullptr;
-    auto next_tap = [&]() {
-        ++ld_tap;
-        ld_cc = 0;
-        tp0 = tp1 = nullptr;
-        if (arow_ok && ld_tap < a.KH * a.KW) {
-            const int kh = ld_tap / a.KW, kw = ld_tap - kh * a.KW;
-            int ys, xs;
-            if (tap_coord<TRANSPOSED>(a, ayd, axd, kh, kw, ys, xs)) {
-                tp0 = a.src0 + (((int64_t)ab * Hl + ys / a.up) * Wl + xs / a.up) * a.C1;
-                if (C2 > 0) tp1 = a.src1 + (((int64_t)ab * a.Hs + ys) * a.Ws + xs) * C2 - a.C1;   // indexed by ci directly
-            }
+    // VEC == 4.  Everything the gather needs per chunk is ONE select and ONE buffer load per slot:
+    //  * operands are addressed through buffer resources with 32-bit byte offsets (tensors < 2 GB, checked by the
+    //    host): structural zeros (padding, stride holes, rows past the end) get an offset beyond num_records and the
+    //    hardware returns 0 -- no branches, no 64-bit address arithmetic in the loop;
+    //  * the K loop is walked tap-major; a slot's pixel offsets change only when the tap changes (every Cin/CB
+    //    chunks) and cost ~25 VALU then; the channel offset of the chunk is wave-uniform and rides in soffset.
+    // (The first version re-derived 64-bit pointers with integer divisions per tap: 1870 non-MFMA VALU instructions
+    // per wave -- and VALU work does not hide under MFMAs: ablation showed T = T_valu + T_mfma, 23 + 27 us on layer1.)
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)a.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0, (int)(a.src1 ? a.bytes1 : 0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.bytesw, 0x00020000);
+    const int cpt = (VEC == 4) ? a.Cin / CB : 1;           // chunks per tap
+    int ld_kh = 0, ld_kw = 0, ld_cc = 0;                     // state of the LOAD stream (runs one chunk ahead)
+    unsigned off0[A_PER], off1[A_PER];                       // byte offsets of (tap pixel, this thread's quad) in src0 / src1
+    auto set_tap = [&]() {
+        const bool tap_ok = ld_kh < a.KH;
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            int ys = 0, xs = 0;
+            const bool ok = tap_ok && arow_ok[j] && tap_coord<TRANSPOSED>(a, ayd[j], axd[j], ld_kh, ld_kw, ys, xs);
+            const unsigned p0 = (unsigned)((ab[j] * Hl + (ys >> sh)) * Wl + (xs >> sh)) * (unsigned)a.C1 + (unsigned)(akq * 4);
+            const unsigned p1 = (unsigned)((ab[j] * a.Hs + ys) * a.Ws + xs) * (unsigned)C2 + (unsigned)(akq * 4);
+            off0[j] = ok ? p0 * 4u : OOB;
+            off1[j] = ok ? p1 * 4u : OOB;
         }
     };
+    auto next_tap = [&]() {
+        ld_cc = 0;
+        if (++ld_kw == a.KW) { ld_kw = 0; ++ld_kh; }
+        set_tap();
+    };
+    unsigned boff[B_PER];                                    // B tile: fixed per-thread offset, the chunk rides in soffset
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+        const int idx = tid + j * NT;                       // over CB x (BN/4)
+        const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
+        const int col = c0 + cq * 4;
+        boff[j] = (idx < B_CNT && col < a.ldw) ? (unsigned)(kr * a.ldw + col) * 4u : OOB;     // ldw % 4 == 0, zero-padded columns
+    }
     if (VEC == 4) {                                          // position the load stream on chunk `cbeg`
-        ld_tap = cbeg / cpt - 1;
-        next_tap();
-        ld_cc = cbeg - (cbeg / cpt) * cpt;
+        const int t0 = cbeg / cpt;
+        ld_kh = t0 / a.KW;
+        ld_kw = t0 - ld_kh * a.KW;
+        ld_cc = cbeg - t0 * cpt;
+        set_tap();
     }
 
     auto load_chunk = [&](int chunk) {
-        const int kbase = chunk * CBK;
+        const int kbase = chunk * CB;
         if (VEC == 4) {
+            const int cbase = ld_cc * CB;                    // wave-uniform: the whole chunk lies on one side of the concat split
+            const bool use0 = cbase < a.C1;
+            const __amdgpu_buffer_rsrc_t rs = use0 ? rs0 : rs1;
+            const int soff = (use0 ? cbase : cbase - a.C1) * 4;
 #pragma unroll
-            for (int j = 0; j < A_PER; ++j) {
-                const int kq = akq0 + j * (NT / BM);
-                f4v v = (f4v){0.f, 0.f, 0.f, 0.f};
-                if (kq < KQ) {
-                    const int ci = ld_cc * CBK + kq * 4;      // Cin % 16 == 0: a quad never straddles a tap or the concat split
-                    const float* p = (ci < a.C1) ? tp0 : tp1;
-                    if (p) v = *(const f4v*)(p + ci);
-                }
-                areg[j] = v;
-            }
+            for (int j = 0; j < A_PER; ++j)
+                areg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs, use0 ? off0[j] : off1[j], soff, 0));
             if (++ld_cc == cpt) next_tap();
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j)
+                breg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsw, boff[j], kbase * a.ldw * 4, 0));
         } else {
 #pragma unroll
             for (int j = 0; j < A_PER; ++j) {
-                const int kq = akq0 + j * (NT / BM);
+                const int kq = akq + j * (NT / BM);
                 const int k = kbase + kq;
                 float v = 0.f;
-                if (arow_ok && kq < KQ && k < K) {
+                if (arow_ok[j] && kq < KQ && k < K) {
                     const int tap = k / a.Cin, ci = k - tap * a.Cin;
                     const int kh = tap / a.KW, kw = tap - kh * a.KW;
                     int ys, xs;
-                    if (tap_coord<TRANSPOSED>(a, ayd, axd, kh, kw, ys, xs))
-                        v = (a.src0[(((int64_t)ab * a.Hs + ys) * a.Ws + xs) * a.Cin + ci] - a.in_sub) * a.in_mul;
+                    if (tap_coord<TRANSPOSED>(a, ayd[j], axd[j], kh, kw, ys, xs))
+                        v = (a.src0[(((int64_t)ab[j] * a.Hs + ys) * a.Ws + xs) * a.Cin + ci] - a.in_sub) * a.in_mul;
                 }
                 areg1[j] = v;
             }
-        }
 #pragma unroll
-        for (int j = 0; j < B_PER; ++j) {
-            const int idx = tid + j * NT;                   // over CBK x (BN/4)
-            const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
-            const int k = kbase + kr, col = c0 + cq * 4;
-            f4v v = (f4v){0.f, 0.f, 0.f, 0.f};
-            if (idx < B_CNT && k < K && col < a.ldw) v = *(const f4v*)(a.w + (int64_t)k * a.ldw + col);   // ldw % 4 == 0, zero-padded columns
-            breg[j] = v;
+            for (int j = 0; j < B_PER; ++j) {
+                const int kr = (tid + j * NT) / (BN / 4);
+                breg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsw, (kbase + kr < K) ? boff[j] : OOB, kbase * a.ldw * 4, 0));
+            }
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
-            const int kq = akq0 + j * (NT / BM);
-            if (kq >= KQ) continue;
             if (VEC == 4) {
+                if (tid + j * NT >= A_CNT) continue;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) As[buf][kq * 4 + e][arow] = areg[j][e];
+                for (int e = 0; e < 4; ++e) As[buf][akq * 4 + e][arow[j]] = areg[j][e];
             } else {
-                As[buf][kq][arow] = areg1[j];
+                const int kq = akq + j * (NT / BM);
+                if (kq < KQ) As[buf][kq][arow[j]] = areg1[j];
             }
         }
 #pragma unroll
@@ -226,7 +262,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         const int buf = (c - cbeg) & 1;
         if (c + 1 < cend) load_chunk(c + 1);                // global loads in flight under the MFMAs below
 #pragma unroll
-        for (int kk = 0; kk < CBK / 2; ++kk) {
+        for (int kk = 0; kk < CB / 2; ++kk) {
             float av[TM], bv[TN];
 #pragma unroll
             for (int u = 0; u < TM; ++u) av[u] = As[buf][kk * 2 + khalf][arow_l + u * 32];
@@ -696,33 +732,43 @@ static int splitk_factor(int64_t Ntot, int Ncols, int K, int vec) {
     if (vec != 4 || Ncols < 64) return 1;
     const int64_t tiles = ((Ntot + 63) / 64) * ((Ncols + 63) / 64);
     if (tiles >= 384) return 1;
-    const int nchunks = (K + CBK - 1) / CBK;
     int64_t S = 768 / tiles;
     if (S > 8) S = 8;
-    if (S > nchunks / 8) S = nchunks / 8;                  // at least 8 chunks (128 k) per slice
+    if (S > K / 128) S = K / 128;                          // at least 128 k per slice
     return S < 2 ? 1 : (int)S;
 }
+
+// K-chunk depth: 32 when the channel count allows (a chunk never straddles a tap; a row's chunk is one 128-byte line)
+#define GEMM_LAUNCH(WM, WN, TM, TN, GRID)                                                                        \
+    do {                                                                                                         \
+        if (cb == 32) hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 4, TR, 32>), GRID, dim3(256), 0, st, a);   \
+        else hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 4, TR, 16>), GRID, dim3(256), 0, st, a);            \
+    } while (0)
 
 template <bool TR>
 static void launch_gemm(ConvArgs a, int vec, float* workspace, hipStream_t st) {
     const int64_t Ntot = (int64_t)a.B * a.Hd * a.Wd;
     const int K = a.KH * a.KW * a.Cin;
     const int S = workspace ? splitk_factor(Ntot, a.Ncols, K, vec) : 1;
+    const int cb = (vec == 4 && a.Cin % 32 == 0 && (a.C1 == a.Cin || a.C1 % 32 == 0)) ? 32 : 16;
     a.ksplit = S; a.cps = 0; a.slab = workspace;
+    a.bytes0 = (int64_t)a.B * (a.Hs / a.up) * (a.Ws / a.up) * a.C1 * 4;
+    a.bytes1 = (int64_t)a.B * a.Hs * a.Ws * (a.Cin - a.C1) * 4;
+    a.bytesw = (int64_t)K * a.ldw * 4;
     if (S > 1) {
-        const int nchunks = (K + CBK - 1) / CBK;
+        const int nchunks = (K + cb - 1) / cb;
         a.cps = (nchunks + S - 1) / S;
         const int Sz = (nchunks + a.cps - 1) / a.cps;
         a.ksplit = Sz;
         dim3 g((unsigned)((Ntot + 63) / 64), (unsigned)((a.Ncols + 63) / 64), (unsigned)Sz);
-        hipLaunchKernelGGL((k_conv_gemm<2, 2, 1, 1, 4, TR>), g, dim3(256), 0, st, a);
+        GEMM_LAUNCH(2, 2, 1, 1, g);
         const int64_t total = Ntot * a.Ncols;
         hipLaunchKernelGGL(k_conv_splitk_epilogue, dim3(egrid(total)), dim3(256), 0, st, workspace, Sz, total, a.Ncols, a.scale, a.shift, a.res, a.out, a.act);
         return;
     }
     if (vec == 1) {
         dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 63) / 64));
-        hipLaunchKernelGGL((k_conv_gemm<4, 1, 1, 2, 1, TR>), g, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_conv_gemm<4, 1, 1, 2, 1, TR, 16>), g, dim3(256), 0, st, a);
         return;
     }
     // tile choice (rows x cols): big tiles reuse each operand fragment twice (half the LDS / L2 traffic per MFMA) but need
@@ -730,19 +776,19 @@ static void launch_gemm(ConvArgs a, int vec, float* workspace, hipStream_t st) {
     auto wgs = [&](int bm, int bn) { return ((Ntot + bm - 1) / bm) * ((a.Ncols + bn - 1) / bn); };
     if (a.Ncols <= 32) {
         dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 31) / 32));
-        hipLaunchKernelGGL((k_conv_gemm<4, 1, 1, 1, 4, TR>), g, dim3(256), 0, st, a);
+        GEMM_LAUNCH(4, 1, 1, 1, g);
     } else if (a.Ncols >= 128 && wgs(128, 128) >= 512) {
         dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 127) / 128));
-        hipLaunchKernelGGL((k_conv_gemm<2, 2, 2, 2, 4, TR>), g, dim3(256), 0, st, a);          // 128 x 128
+        hipLaunchKernelGGL((k_conv_gemm<2, 2, 2, 2, 4, TR, 16>), g, dim3(256), 0, st, a);      // 128 x 128 (depth 32 would need > 64 KB of LDS)
     } else if (wgs(128, 64) >= 512) {
         dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 63) / 64));
-        hipLaunchKernelGGL((k_conv_gemm<2, 2, 2, 1, 4, TR>), g, dim3(256), 0, st, a);          // 128 x 64
+        GEMM_LAUNCH(2, 2, 2, 1, g);                                                            // 128 x 64
     } else if (wgs(64, 64) >= 256 || a.Ncols < 128) {
         dim3 g((unsigned)((Ntot + 63) / 64), (unsigned)((a.Ncols + 63) / 64));
-        hipLaunchKernelGGL((k_conv_gemm<2, 2, 1, 1, 4, TR>), g, dim3(256), 0, st, a);          // 64 x 64
+        GEMM_LAUNCH(2, 2, 1, 1, g);                                                            // 64 x 64
     } else {
         dim3 g((unsigned)((Ntot + 31) / 32), (unsigned)((a.Ncols + 127) / 128));
-        hipLaunchKernelGGL((k_conv_gemm<1, 4, 1, 1, 4, TR>), g, dim3(256), 0, st, a);          // 32 x 128
+        GEMM_LAUNCH(1, 4, 1, 1, g);                                                            // 32 x 128
     }
 }
 
@@ -774,8 +820,10 @@ int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const f
     E2E_REQUIRE(pad_mode == 0 || (pad_mode == 1 && pad == 1 && Hs >= 2 && Ws >= 2), E2E_ERR_ARG, "e2e_conv2d_fwd: reflection padding needs pad == 1");
     E2E_REQUIRE(stride == 1 || stride == 2, E2E_ERR_ARG, "e2e_conv2d_fwd: stride must be 1 or 2");
     E2E_REQUIRE(Hs % up == 0 && Ws % up == 0 && ld_fwd % 4 == 0 && ld_fwd >= Cout, E2E_ERR_ARG, "e2e_conv2d_fwd: bad sizes");
-    const int vec = (Cin % 16 == 0 && C1 % 4 == 0 && (Cin - C1) % 4 == 0) ? 4 : 1;
+    const int vec = (Cin % 16 == 0 && (C1 == Cin || C1 % 16 == 0)) ? 4 : 1;
     E2E_REQUIRE(vec == 4 || (C1 == Cin && up == 1), E2E_ERR_ARG, "e2e_conv2d_fwd: the scalar path (Cin %% 16 != 0) takes a single full-resolution source");
+    E2E_REQUIRE((int64_t)B * Hs * Ws * Cin * 4 < (1ll << 31) && (int64_t)KH * KW * Cin * ld_fwd * 4 < (1ll << 31), E2E_ERR_ARG,
+                "e2e_conv2d_fwd: operands must stay below 2 GB (32-bit buffer offsets)");
     ConvArgs a{};
     a.src0 = src0; a.src1 = src1; a.w = w_fwd; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
     a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cin = Cin; a.C1 = C1; a.up = up;
@@ -791,6 +839,8 @@ int e2e_conv2d_bwd_data(const float* dz, const float* w_bwd, int ld_bwd, float* 
                         int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, float* workspace, void* stream) {
     E2E_REQUIRE(dz && w_bwd && dxp && B > 0 && Cin > 0 && Cout > 0 && Cout % 16 == 0, E2E_ERR_ARG, "e2e_conv2d_bwd_data: bad argument (Cout %% 16 == 0)");
     E2E_REQUIRE(ld_bwd % 4 == 0 && ld_bwd >= Cin && (stride == 1 || stride == 2), E2E_ERR_ARG, "e2e_conv2d_bwd_data: bad sizes");
+    E2E_REQUIRE((int64_t)B * Ho * Wo * Cout * 4 < (1ll << 31) && (int64_t)KH * KW * Cout * ld_bwd * 4 < (1ll << 31), E2E_ERR_ARG,
+                "e2e_conv2d_bwd_data: operands must stay below 2 GB (32-bit buffer offsets)");
     ConvArgs a{};
     a.src0 = dz; a.src1 = nullptr; a.w = w_bwd; a.out = dxp;
     a.B = B; a.Hs = Ho; a.Ws = Wo; a.Cin = Cout; a.C1 = Cout; a.up = 1;
