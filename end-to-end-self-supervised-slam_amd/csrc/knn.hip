@@ -78,19 +78,22 @@ __global__ __launch_bounds__(KT) void k_knn1_bwd(const float* __restrict__ g, co
 
 // ---------------------------------------------------------------------------------------------
 // Exact uniform-grid acceleration (results identical to the brute force, ties included).
-//   build : bbox (integer atomics on order-preserving keys) -> cell size h = max(extent/GRID_MAX, H_MIN) ->
+//   build : bbox (integer atomics on order-preserving keys) -> cell size h = max(extent/(G-1), H_MIN), G = 128 or 256 ->
 //           per-cell counts -> exclusive scan -> counting-sort scatter of (x,y,z,index) float4s
 //   query : one query per lane; visit the cube of radius r cells around the query's cell, shell by shell, keeping
 //           the lexicographic minimum of (distance, index); stop as soon as the best distance is strictly below
 //           the (safety-shrunk) distance to the nearest unexplored face -- nothing outside can tie or win.
-//           Queries still unresolved after radius GRID_RMAX are finished by a brute-force scan (one workgroup
-//           per such query).
+//           Rows / cells whose lower-bound distance exceeds the best distance so far are skipped (exact: <= keeps ties).
+//           Queries still unresolved after radius GRID_RMAX are finished by k_knn1_rest, one wave per query.
 // Intra-cell order after the scatter depends on atomic arrival order, but min over (distance, index) does not.
 // ---------------------------------------------------------------------------------------------
-#define GRID_MAX 128
-#define GRID_CELLS_CAP (GRID_MAX * GRID_MAX * GRID_MAX)
-#define GRID_HMIN 0.02f
-#define GRID_RMAX 6
+#define GRID_MAX_SMALL 128    // cells per axis: reference sets below GRID_BIG_N2 points
+#define GRID_MAX_BIG 256      // ... and above: a map of millions of SURFACE points puts ~300 points in each occupied cell of a
+#define GRID_BIG_N2 1500000   //     128^3 grid (measured: 1.9 ms per query pass at 5 M points); halving h quarters that
+static inline int grid_max_for(int64_t n2) { return n2 >= GRID_BIG_N2 ? GRID_MAX_BIG : GRID_MAX_SMALL; }
+static inline int64_t grid_cells_cap(int64_t n2) { const int64_t g = grid_max_for(n2); return g * g * g; }
+#define GRID_HMIN 0.01f
+#define GRID_RMAX 2      // shells of the one-query-per-lane pass; whatever it cannot bound goes to the wave-per-query pass
 #define SCAN_BLOCK 1024
 
 struct GridInfo {
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(KT) void k_grid_bbox(const float* __restrict__ p, i
     }
 }
 
-__global__ __launch_bounds__(BBOX_BLOCKS) void k_grid_setup(GridInfo* gi, const unsigned int* __restrict__ part, int nparts) {
+__global__ __launch_bounds__(BBOX_BLOCKS) void k_grid_setup(GridInfo* gi, const unsigned int* __restrict__ part, int nparts, int gmax) {
     __shared__ unsigned int sh[6][BBOX_BLOCKS / 64];
     for (int c = 0; c < 6; ++c) {
         unsigned int v = (threadIdx.x < nparts) ? part[threadIdx.x * 6 + c] : (c < 3 ? 0xFFFFFFFFu : 0u);
@@ -173,13 +176,13 @@ __global__ __launch_bounds__(BBOX_BLOCKS) void k_grid_setup(GridInfo* gi, const 
         lo[c] = fkey_inv(gi->bb[c]);
         ext = fmaxf(ext, fkey_inv(gi->bb[3 + c]) - lo[c]);
     }
-    const float h = fmaxf(ext / (float)(GRID_MAX - 1), GRID_HMIN);
+    const float h = fmaxf(ext / (float)(gmax - 1), GRID_HMIN);
     gi->h = h;
     gi->inv_h = 1.0f / h;
     for (int c = 0; c < 3; ++c) {
         gi->origin[c] = lo[c];
         int d = (int)floorf((fkey_inv(gi->bb[3 + c]) - lo[c]) / h) + 1;
-        gi->dims[c] = min(max(d, 1), GRID_MAX);
+        gi->dims[c] = min(max(d, 1), gmax);
     }
 }
 
@@ -295,19 +298,36 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
         int lo[3], hi[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) { lo[c] = max(cq[c] - r, 0); hi[c] = min(cq[c] + r, dims[c] - 1); }
-        for (int cz = lo[2]; cz <= hi[2]; ++cz)
+        for (int cz = lo[2]; cz <= hi[2]; ++cz) {
+            // Pruning (exact): a cell row / cell can only matter if its lower-bound distance to the query does not exceed
+            // the best distance so far (<=, a tie with a smaller index may hide there).  Bounds are shrunk by the same
+            // safety margin as the stop test because points sit in their cells only up to fp32 rounding.
+            const float gz = fmaxf(fmaxf(org[2] + (float)cz * h - z, z - (org[2] + (float)(cz + 1) * h)), 0.f);
+            const float gzs = fmaxf(gz * 0.999f - 1e-5f, 0.f);
+            if (gzs * gzs > bd) continue;
             for (int cy = lo[1]; cy <= hi[1]; ++cy) {
+                const float gy = fmaxf(fmaxf(org[1] + (float)cy * h - y, y - (org[1] + (float)(cy + 1) * h)), 0.f);
+                const float gys = fmaxf(gy * 0.999f - 1e-5f, 0.f);
+                const float dyz = gzs * gzs + gys * gys;
+                if (dyz > bd) continue;
                 // cells of one (cz,cy) row are consecutive => their points form ONE contiguous range of `sorted`.
                 // A row that was already inside the previous cube only contributes its two new end segments.
                 const bool row_in_prev = cz >= pl[2] && cz <= ph[2] && cy >= pl[1] && cy <= ph[1];
                 const unsigned int rowbase = (unsigned int)((cz * dims[1] + cy) * dims[0]);
                 int seg_lo[2] = {lo[0], 0}, seg_hi[2] = {hi[0], -1};
                 if (row_in_prev) { seg_hi[0] = pl[0] - 1; seg_lo[1] = ph[0] + 1; seg_hi[1] = hi[0]; }
+                int xlo = lo[0], xhi = hi[0];
+                if (bd < 3.0e38f) {                                 // x extent of the ball of radius sqrt(bd) at this row, inflated
+                    const float rx = sqrtf(bd - dyz) * 1.001f + 2e-5f;
+                    xlo = max(xlo, (int)floorf(fmaxf((x - rx - org[0]) * ih, -1.f)));
+                    xhi = min(xhi, (int)floorf(fminf((x + rx - org[0]) * ih, 1.0e6f)));
+                }
 #pragma unroll
                 for (int sgm = 0; sgm < 2; ++sgm) {
-                    if (seg_lo[sgm] > seg_hi[sgm]) continue;
-                    unsigned int k = starts[rowbase + seg_lo[sgm]];
-                    const unsigned int e = starts[rowbase + seg_hi[sgm] + 1];
+                    const int s0 = max(seg_lo[sgm], xlo), s1 = min(seg_hi[sgm], xhi);
+                    if (s0 > s1) continue;
+                    unsigned int k = starts[rowbase + s0];
+                    const unsigned int e = starts[rowbase + s1 + 1];
                     for (; k + 4 <= e; k += 4) {
                         float4 t[4];
 #pragma unroll
@@ -329,6 +349,7 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
                     }
                 }
             }
+        }
         // lower bound on the distance to any point outside the explored cube
         float db = 3.402823466e38f;
 #pragma unroll
@@ -359,32 +380,90 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
     }
 }
 
-// brute force for the queries the grid could not bound: one workgroup per query
-__global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, const float* __restrict__ p2, int64_t n2,
-                                                  const GridInfo* __restrict__ gi, const unsigned int* __restrict__ unresolved,
-                                                  float* __restrict__ dists, long long* __restrict__ idx) {
-    __shared__ unsigned long long sh[KT / 64];
+// Queries the per-lane pass could not bound within GRID_RMAX shells (they look at a part of the scene the map does not
+// cover yet) are finished by ONE WAVE each: same shell search, the (cz,cy) rows of every shell spread over the 64
+// lanes, (distance, index) keys combined with integer min.  While nothing has been found the radius doubles.  Worst
+// case every point of the grid is visited once -- the brute force this replaces read all n2 points per query.
+__global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, const GridInfo* __restrict__ gi,
+                                                  const unsigned int* __restrict__ starts, const float4* __restrict__ sorted,
+                                                  const unsigned int* __restrict__ unresolved, float* __restrict__ dists,
+                                                  long long* __restrict__ idx) {
     const unsigned int cnt = gi->n_unresolved;
-    for (unsigned int u = blockIdx.x; u < cnt; u += gridDim.x) {
+    const int lane = threadIdx.x & 63;
+    const unsigned int wave0 = blockIdx.x * (KT / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (KT / 64);
+    const float h = gi->h, ih = gi->inv_h;
+    const int dims[3] = {gi->dims[0], gi->dims[1], gi->dims[2]};
+    const float org[3] = {gi->origin[0], gi->origin[1], gi->origin[2]};
+    for (unsigned int u = wave0; u < cnt; u += nwaves) {
         const unsigned int i = unresolved[u];
         const float x = p1[(int64_t)i * 3], y = p1[(int64_t)i * 3 + 1], z = p1[(int64_t)i * 3 + 2];
-        unsigned long long best = 0xFFFFFFFFFFFFFFFFull;
-        for (int64_t j = threadIdx.x; j < n2; j += KT) {
-            const float dx = x - p2[j * 3], dy = y - p2[j * 3 + 1], dz = z - p2[j * 3 + 2];
-            const float d = (dx * dx + dy * dy) + dz * dz;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)j;
-            best = (key < best) ? key : best;
-        }
+        const float q[3] = {x, y, z};
+        int cq[3];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_down(best, o, 64);
-            best = (other < best) ? other : best;
+        for (int c = 0; c < 3; ++c) cq[c] = cell_coord(q[c], org[c], ih, dims[c]);
+        unsigned long long best = 0xFFFFFFFFFFFFFFFFull;
+        int pl[3] = {0, 0, 0}, ph[3] = {-1, -1, -1};
+        int r = 0;
+        while (true) {
+            int lo[3], hi[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { lo[c] = max(cq[c] - r, 0); hi[c] = min(cq[c] + r, dims[c] - 1); }
+            const int ny = hi[1] - lo[1] + 1, nrows = ny * (hi[2] - lo[2] + 1);
+            const float bd0 = __uint_as_float((unsigned int)(best >> 32));   // wave-uniform bound from the previous shells
+            for (int t = lane; t < nrows; t += 64) {
+                const int cz = lo[2] + t / ny, cy = lo[1] + t % ny;
+                const bool row_in_prev = cz >= pl[2] && cz <= ph[2] && cy >= pl[1] && cy <= ph[1];
+                const unsigned int rowbase = (unsigned int)((cz * dims[1] + cy) * dims[0]);
+                int seg_lo[2] = {lo[0], 0}, seg_hi[2] = {hi[0], -1};
+                if (row_in_prev) { seg_hi[0] = pl[0] - 1; seg_lo[1] = ph[0] + 1; seg_hi[1] = hi[0]; }
+                int xlo = lo[0], xhi = hi[0];
+                if (best != 0xFFFFFFFFFFFFFFFFull) {           // same exact ball pruning as the per-lane pass
+                    const float gz = fmaxf(fmaxf(org[2] + (float)cz * h - z, z - (org[2] + (float)(cz + 1) * h)), 0.f);
+                    const float gy = fmaxf(fmaxf(org[1] + (float)cy * h - y, y - (org[1] + (float)(cy + 1) * h)), 0.f);
+                    const float gzs = fmaxf(gz * 0.999f - 1e-5f, 0.f), gys = fmaxf(gy * 0.999f - 1e-5f, 0.f);
+                    const float dyz = gzs * gzs + gys * gys;
+                    if (dyz > bd0) continue;
+                    const float rx = sqrtf(bd0 - dyz) * 1.001f + 2e-5f;
+                    xlo = max(xlo, (int)floorf(fmaxf((x - rx - org[0]) * ih, -1.f)));
+                    xhi = min(xhi, (int)floorf(fminf((x + rx - org[0]) * ih, 1.0e6f)));
+                }
+#pragma unroll
+                for (int sgm = 0; sgm < 2; ++sgm) {
+                    const int s0 = max(seg_lo[sgm], xlo), s1 = min(seg_hi[sgm], xhi);
+                    if (s0 > s1) continue;
+                    const unsigned int e = starts[rowbase + s1 + 1];
+                    for (unsigned int k = starts[rowbase + s0]; k < e; ++k) {
+                        const float4 tq = sorted[k];
+                        const float dx = x - tq.x, dy = y - tq.y, dz = z - tq.z;
+                        const float d = (dx * dx + dy * dy) + dz * dz;
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(tq.w);
+                        best = (key < best) ? key : best;
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {                 // all lanes end up with the wave minimum
+                const unsigned long long other = __shfl_xor(best, o, 64);
+                best = (other < best) ? other : best;
+            }
+            float db = 3.402823466e38f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (lo[c] > 0) db = fminf(db, q[c] - (org[c] + (float)lo[c] * h));
+                if (hi[c] < dims[c] - 1) db = fminf(db, (org[c] + (float)(hi[c] + 1) * h) - q[c]);
+            }
+            if (db >= 3.0e38f) break;                          // the whole grid has been visited
+            const float bd = __uint_as_float((unsigned int)(best >> 32));
+            const float dbe = db * 0.999f - 1e-5f;
+            if (best != 0xFFFFFFFFFFFFFFFFull && dbe > 0.f && bd < dbe * dbe) break;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { pl[c] = lo[c]; ph[c] = hi[c]; }
+            // nothing found yet: double the radius.  Something found at distance sqrt(bd): no closer point can lie outside
+            // the cube of that half-width, so jump straight to the radius that bounds it.
+            if (best == 0xFFFFFFFFFFFFFFFFull) r = max(r + 1, 2 * r);
+            else r = max(r + 1, (int)fminf(ceilf(sqrtf(bd) * ih) + 1.f, 1.0e6f));
         }
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = best;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < KT / 64; ++w) best = (sh[w] < best) ? sh[w] : best;
+        if (lane == 0) {
             dists[i] = __uint_as_float((unsigned int)(best >> 32));
             idx[i] = (long long)(best & 0xFFFFFFFFull);
         }
@@ -397,7 +476,7 @@ static int knn1_brute(const float* p1, int64_t n1, const float* p2, int64_t n2, 
 #define KNN_GRID_MIN_N2 8192      // below this the brute force is already cheap
 
 static int64_t grid_ws_bytes(int64_t n1, int64_t n2) {
-    const int64_t nc = GRID_CELLS_CAP, nb = (nc + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    const int64_t nc = grid_cells_cap(n2), nb = (nc + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
     // GridInfo | counts[nc+1] | starts[nc+1] | fill[nc] | bsum[nb] | cell_of[n2] | unresolved[n1] | sorted float4[n2]
     return 256 + 4 * (nc + 1) * 2 + 4 * nc + 4 * (nb + 1) + 4 * 6 * BBOX_BLOCKS + 4 * n2 + 4 * n1 + 64 + 16 * n2;
 }
@@ -410,7 +489,7 @@ int64_t e2e_knn1_workspace_bytes(int64_t n1, int64_t n2) {
 }
 
 static int knn1_grid(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists, long long* idx, void* workspace, hipStream_t st) {
-    const int64_t nc = GRID_CELLS_CAP, nscan = nc + 1;
+    const int64_t nc = grid_cells_cap(n2), nscan = nc + 1;
     const int nb = (int)((nscan + SCAN_BLOCK - 1) / SCAN_BLOCK);
     char* w = (char*)workspace;
     GridInfo* gi = (GridInfo*)w; w += 256;
@@ -427,14 +506,14 @@ static int knn1_grid(const float* p1, int64_t n1, const float* p2, int64_t n2, f
     hipLaunchKernelGGL(k_grid_init, dim3(2048), dim3(256), 0, st, gi, counts, fill, nc);
     const int bb_blocks = gp > BBOX_BLOCKS ? BBOX_BLOCKS : gp;
     hipLaunchKernelGGL(k_grid_bbox, dim3(bb_blocks), dim3(KT), 0, st, p2, n2, bbpart);
-    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(BBOX_BLOCKS), 0, st, gi, bbpart, bb_blocks);
+    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(BBOX_BLOCKS), 0, st, gi, bbpart, bb_blocks, grid_max_for(n2));
     hipLaunchKernelGGL(k_grid_count, dim3(gp), dim3(KT), 0, st, p2, n2, gi, cell_of, counts);
     hipLaunchKernelGGL(k_scan_blocksum, dim3(nb), dim3(KT), 0, st, counts, nscan, bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, bsum, nb);
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(KT), 0, st, counts, nscan, bsum, starts);
     hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(KT), 0, st, p2, n2, cell_of, starts, fill, sorted);
     hipLaunchKernelGGL(k_grid_query, dim3((unsigned)((n1 + KT - 1) / KT)), dim3(KT), 0, st, p1, n1, gi, starts, sorted, dists, idx, unresolved);
-    hipLaunchKernelGGL(k_knn1_rest, dim3(1024), dim3(KT), 0, st, p1, p2, n2, gi, unresolved, dists, idx);
+    hipLaunchKernelGGL(k_knn1_rest, dim3(1024), dim3(KT), 0, st, p1, gi, starts, sorted, unresolved, dists, idx);
     return E2E_OK;
 }
 

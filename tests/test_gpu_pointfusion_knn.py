@@ -194,7 +194,7 @@ def test_knn_full_frame_properties():
     assert torch.equal(d[:2000].cpu(), dr) and torch.equal(i[:2000].cpu(), ir)
 
 
-@pytest.mark.parametrize("case", ["surface", "clustered", "far_queries", "degenerate"])
+@pytest.mark.parametrize("case", ["surface", "clustered", "far_queries", "degenerate", "big_map", "sparse_far"])
 def test_knn_grid_equals_brute(case):
     """The grid search must return exactly what the brute force returns (distances AND indices, ties included) on
     surface-like data, heavy clusters with duplicates, queries far outside the reference set, and a degenerate cloud."""
@@ -213,6 +213,18 @@ def test_knn_grid_equals_brute(case):
     elif case == "far_queries":
         ref = torch.rand(20000, 3, generator=g)
         q = torch.cat([torch.rand(3000, 3, generator=g) * 40 - 20, torch.rand(3000, 3, generator=g)], 0)
+    elif case == "big_map":        # > 1.5 M surface points: the 256^3 grid; a third of the queries look at unmapped space
+        n = 1_800_000
+        u = torch.rand(n, 2, generator=g) * 8 - 4
+        ref = torch.stack([u[:, 0], 1.2 * torch.cos(u[:, 1]) + 0.001 * torch.randn(n, generator=g), u[:, 1]], 1)
+        ref[5000:5300] = ref[11]                                 # duplicates
+        v = torch.rand(20000, 2, generator=g) * 8 - 4
+        near = torch.stack([v[:, 0], 1.2 * torch.cos(v[:, 1]) + 0.01, v[:, 1]], 1)
+        far = torch.rand(10000, 3, generator=g) * torch.tensor([20.0, 6.0, 20.0]) - torch.tensor([10.0, 3.0, 10.0])
+        q = torch.cat([near, far, ref[11:12], ref[5100:5101]], 0)
+    elif case == "sparse_far":     # tiny clusters far apart: the finishing pass has to double its radius through empty space
+        ref = torch.cat([0.01 * torch.randn(6000, 3, generator=g), 0.01 * torch.randn(6000, 3, generator=g) + 30.0], 0)
+        q = torch.cat([torch.rand(4000, 3, generator=g) * 30, 0.01 * torch.randn(500, 3, generator=g) + 30.0], 0)
     else:
         ref = torch.zeros(9000, 3) + 1.5                          # zero extent
         q = torch.rand(2000, 3, generator=g)
