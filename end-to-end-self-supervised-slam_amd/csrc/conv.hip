@@ -551,6 +551,27 @@ __global__ __launch_bounds__(256) void k_weight_layouts(const float* __restrict_
     }
 }
 
+// all layers of a network in ONE launch (after an optimiser step every layout is stale): blockIdx.y = layer, descriptor
+// table of 10 int64 per layer on the device: {w, w_fwd, w_bwd, Cout, Cin, KH, KW, ld_fwd, ld_bwd, reserved}
+__global__ __launch_bounds__(256) void k_weight_layouts_batched(const long long* __restrict__ desc) {
+    const long long* d = desc + (int64_t)blockIdx.y * 10;
+    const float* w = (const float*)d[0];
+    float* wf = (float*)d[1];
+    float* wb = (float*)d[2];
+    const int Cout = (int)d[3], Cin = (int)d[4], KH = (int)d[5], KW = (int)d[6], ldf = (int)d[7], ldb = (int)d[8];
+    const int64_t total = (int64_t)Cout * Cin * KH * KW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t t = i;
+        const int kw = (int)(t % KW); t /= KW;
+        const int kh = (int)(t % KH); t /= KH;
+        const int ci = (int)(t % Cin); t /= Cin;
+        const int co = (int)t;
+        const float v = w[i];
+        if (wf) wf[((int64_t)(kh * KW + kw) * Cin + ci) * ldf + co] = v;
+        if (wb) wb[((int64_t)(kh * KW + kw) * Cout + co) * ldb + ci] = v;
+    }
+}
+
 // dZ = dY * act'(Y) * scale[c]     (Y = the activation's OUTPUT; ELU' = y+1 for y<=0; DISP' = (y-.01)(1-(y-.01)/10))
 __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ scale,
                                                  float* __restrict__ dz, int64_t n, int C, int act) {
@@ -802,6 +823,13 @@ int e2e_conv_weight_layouts(const float* w, int Cout, int Cin, int KH, int KW, f
     hipLaunchKernelGGL(k_weight_layouts, dim3(egrid((int64_t)Cout * Cin * KH * KW)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, KH,
                        KW, w_fwd, ld_fwd, w_bwd, ld_bwd);
     E2E_LAUNCH_CHECK("e2e_conv_weight_layouts");
+    return E2E_OK;
+}
+
+int e2e_conv_weight_layouts_batched(const long long* desc, int nlayers, void* stream) {
+    E2E_REQUIRE(desc && nlayers > 0 && nlayers <= 65535, E2E_ERR_ARG, "e2e_conv_weight_layouts_batched: bad argument");
+    hipLaunchKernelGGL(k_weight_layouts_batched, dim3(256, nlayers), dim3(256), 0, (hipStream_t)stream, desc);
+    E2E_LAUNCH_CHECK("e2e_conv_weight_layouts_batched");
     return E2E_OK;
 }
 

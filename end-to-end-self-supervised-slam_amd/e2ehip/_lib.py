@@ -68,6 +68,7 @@ SIGNATURES = {
     "e2e_depth_metrics": [c_fp, c_fp, c_i64, c_int, c_fp, c_fp, c_fp],
     "e2e_adam_step": [c_fp, c_fp, c_fp, c_fp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_fp],
     "e2e_conv_weight_layouts": [c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_int, c_fp],
+    "e2e_conv_weight_layouts_batched": [c_fp, c_int, c_fp],
     "e2e_conv2d_fwd": [c_fp, c_fp, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp] + [c_int] * 11 + [c_f32, c_f32, c_fp, c_fp],
     "e2e_conv2d_splitk_workspace_floats": [c_i64, c_int, c_int],
     "e2e_conv2d_act_bwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp],

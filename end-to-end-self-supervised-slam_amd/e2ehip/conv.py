@@ -1,6 +1,8 @@
 """Native convolutions of the depth network (csrc/conv.hip): fp32-MFMA implicit GEMM with the gather
 (stride, zero / reflection padding, nearest x2 upsample + channel concat) and the epilogue (folded eval-BN /
 bias, residual add, ReLU / ELU / disparity head) fused.  Tensors are NCHW-shaped, channels_last in memory."""
+import weakref
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -14,24 +16,62 @@ CL = torch.channels_last
 WEIGHT_EPOCH = [0]
 
 
+_REGISTRY = []          # weak references to every weight that owns layout buffers
+_DESC = {}              # device -> (signature of the table, device tensor of descriptors)
+
+
 def _weight_layouts(w, want_bwd):
-    """The cache entry lives ON the weight tensor object (a recycled allocation of another tensor can therefore never
-    alias it); it is valid while (data_ptr, torch version counter, FusedAdam epoch) are unchanged."""
-    Cout, Cin, KH, KW = w.shape
+    """k-major GEMM copies of a weight.  The entry lives ON the weight tensor object (a recycled allocation of another
+    tensor can never alias it) and is valid while (data_ptr, torch version counter, FusedAdam epoch) are unchanged.
+    The buffers are allocated once and rewritten in place; when an entry is stale, EVERY stale registered weight on the
+    device is refreshed in the same launch (after an optimiser step that is all of them: 1 launch instead of ~40)."""
     key = (w.data_ptr(), w._version, WEIGHT_EPOCH[0])
-    hit = getattr(w, "_e2e_layouts", None)
-    if hit is not None and hit[0] == key and (hit[2] is not None or not want_bwd):
-        return hit[1], hit[2]
+    ent = getattr(w, "_e2e_layouts", None)
+    if ent is not None and ent["key"] == key and (ent["wb"] is not None or not want_bwd):
+        return ent["wf"], ent["wb"]
+    Cout, Cin, KH, KW = w.shape
     ldf, ldb = _ld(Cout), _ld(Cin)
-    mk = lambda rows, ld, exact: (torch.empty if exact else torch.zeros)(rows, ld, device=w.device, dtype=torch.float32)
-    wf = mk(KH * KW * Cin, ldf, ldf == Cout)
-    wb = mk(KH * KW * Cout, ldb, ldb == Cin) if want_bwd else None
-    L.call("e2e_conv_weight_layouts", L.ptr(w), Cout, Cin, KH, KW, L.ptr(wf), ldf, L.ptr(wb), ldb, L.stream())
-    try:
-        w._e2e_layouts = (key, wf, wb)
-    except AttributeError:
-        pass
-    return wf, wb
+    if ent is None:
+        ent = {"key": None, "wf": torch.zeros(KH * KW * Cin, ldf, device=w.device, dtype=torch.float32), "wb": None}
+        try:
+            w._e2e_layouts = ent
+            _REGISTRY.append(weakref.ref(w))
+        except AttributeError:                      # cannot attach (exotic tensor subclass): uncached single refresh
+            wb = torch.zeros(KH * KW * Cout, ldb, device=w.device, dtype=torch.float32) if want_bwd else None
+            L.call("e2e_conv_weight_layouts", L.ptr(w), Cout, Cin, KH, KW, L.ptr(ent["wf"]), ldf, L.ptr(wb), ldb, L.stream())
+            return ent["wf"], wb
+    if want_bwd and ent["wb"] is None:
+        ent["wb"] = torch.zeros(KH * KW * Cout, ldb, device=w.device, dtype=torch.float32)
+        ent["key"] = None
+    _refresh_stale(w.device)
+    return ent["wf"], ent["wb"]
+
+
+def _refresh_stale(device):
+    rows, sig, live = [], [], []
+    for r in _REGISTRY:
+        t = r()
+        if t is None:
+            continue
+        live.append(r)
+        ent = t._e2e_layouts
+        key = (t.data_ptr(), t._version, WEIGHT_EPOCH[0])
+        if t.device != device or ent["key"] == key:
+            continue
+        Cout, Cin, KH, KW = t.shape
+        rows.append([t.data_ptr(), ent["wf"].data_ptr(), ent["wb"].data_ptr() if ent["wb"] is not None else 0,
+                     Cout, Cin, KH, KW, _ld(Cout), _ld(Cin), 0])
+        sig.append((t.data_ptr(), ent["wf"].data_ptr(), rows[-1][2]))
+        ent["key"] = key
+    _REGISTRY[:] = live
+    if not rows:
+        return
+    sig = tuple(sig)
+    cached = _DESC.get(device)
+    if cached is None or cached[0] != sig:
+        cached = (sig, torch.tensor(rows, dtype=torch.int64).to(device))
+        _DESC[device] = cached
+    L.call("e2e_conv_weight_layouts_batched", L.ptr(cached[1]), len(rows), L.stream())
 
 
 def available():

@@ -198,7 +198,7 @@ class SLAM:
         coordinates through its pose) is transformed AGAIN by T (reference quirk) and pulled
         towards its nearest neighbours in the detached global map."""
         maps = ops.vertex_normal_maps(d_tgt.reshape(1, self.H, self.W), K, pose_tgt, self.map.sigma)
-        cloud = maps["Vg"][0][maps["valid"][0]]
+        cloud = ops.select_rows(maps["Vg"][0].reshape(-1, 3), maps["valid"][0].reshape(-1))
         moved = ops.transform_points(cloud, T[0])
         d, _ = ops.knn1(moved, self.map.points[: self.map.M])
         return d.mean()

@@ -283,6 +283,11 @@ int e2e_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
 int e2e_conv_weight_layouts(const float* w, int Cout, int Cin, int KH, int KW, float* w_fwd,
                             int ld_fwd, float* w_bwd, int ld_bwd, void* stream);
 
+/* The same for `nlayers` layers in one launch (all layouts go stale together after an optimiser
+ * step).  `desc`: DEVICE array of 10 int64 per layer {w, w_fwd, w_bwd (addresses, 0 = skip), Cout,
+ * Cin, KH, KW, ld_fwd, ld_bwd, 0}. */
+int e2e_conv_weight_layouts_batched(const long long* desc, int nlayers, void* stream);
+
 /* out (B,Ho,Wo,Cout) = act( scale[c] * conv(x) + shift[c] (+ residual) ), x = the VIRTUAL input
  * cat( nearest_upsample(src0 (B,Hs/up,Ws/up,C1), up), src1 (B,Hs,Ws,Cin-C1) ) padded by `pad`
  * (pad_mode 0 zeros, 1 reflection) -- upsample, concat and padding are gather arithmetic, never
