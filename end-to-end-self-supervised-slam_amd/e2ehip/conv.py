@@ -16,6 +16,31 @@ CL = torch.channels_last
 WEIGHT_EPOCH = [0]
 
 
+# Gradient sinks.  FusedAdam keeps every gradient in one flat buffer; inside `direct_weight_grads()` the backward-weight
+# kernels ACCUMULATE straight into a parameter's slice of that buffer (`p._e2e_grad_sink`, installed by FlatParams) and
+# return no gradient for it, which removes one AccumulateGrad add kernel per parameter and step (48 at 5 us).  Off by
+# default: torch.autograd.grad() callers must get their gradients returned.
+DIRECT_WGRAD = [False]
+
+
+class direct_weight_grads:
+    def __enter__(self):
+        self.prev = DIRECT_WGRAD[0]
+        DIRECT_WGRAD[0] = True
+
+    def __exit__(self, *exc):
+        DIRECT_WGRAD[0] = self.prev
+
+
+def _sink(param, shape):
+    if not DIRECT_WGRAD[0] or param is None:
+        return None
+    t = getattr(param, "_e2e_grad_sink", None)
+    if t is None or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or t.dtype != torch.float32:
+        return None
+    return t
+
+
 _REGISTRY = []          # weak references to every weight that owns layout buffers
 _DESC = {}              # device -> (signature of the table, device tensor of descriptors)
 
@@ -98,6 +123,7 @@ class _Head(torch.autograd.Function):
         L.call("e2e_head_fwd", L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), B, H, W, C, act, L.stream())
         ctx.save_for_backward(x, w, y)
         ctx.cfg = (act, bias is not None)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -117,6 +143,14 @@ class _Head(torch.autograd.Function):
         db = torch.empty(1, device=g.device, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
         ws = torch.empty(L.load().e2e_head_workspace_floats(), device=g.device, dtype=torch.float32)
         L.call("e2e_head_bwd", L.ptr(dz), L.ptr(x), L.ptr(w), L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws), B, H, W, C, st)
+        sw = _sink(ctx.params[0], w.shape) if dw is not None else None
+        sb = _sink(ctx.params[1], (1,)) if db is not None else None
+        if sw is not None:                          # tiny tensors (145 numbers): add in place, return nothing
+            sw.add_(dw)
+            dw = None
+        if sb is not None:
+            sb.add_(db)
+            db = None
         return dx, dw, db, None
 
 
@@ -131,6 +165,7 @@ def _ld(n):
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src0, src1, weight, bias, scale, shift, residual, up, stride, pad, pad_mode, act, in_norm, wf, wb):
+        ctx.params = (weight, bias)
         Cout, Cin, KH, KW = weight.shape
         src0 = _cl(L.dev(src0, "input"))
         B, C1 = src0.shape[0], src0.shape[1]
@@ -207,12 +242,18 @@ class _Conv2d(torch.autograd.Function):
                     g1 = torch.empty(B, Cin - C1, Hs, Ws, device=dev, dtype=torch.float32, memory_format=CL)
                 L.call("e2e_conv2d_gather_adjoint", L.ptr(dxp), B, Hs, Ws, Cin, C1, up, 1 if pp else 0, L.ptr(g0), L.ptr(g1), 0, 0, st)
         if needs[2]:
-            gw = torch.empty(Cout, Cin, KH, KW, device=dev, dtype=torch.float32)
-            gb = torch.empty(Cout, device=dev, dtype=torch.float32) if (has_bias and needs[3]) else None
+            want_b = has_bias and needs[3]
+            sw = _sink(ctx.params[0], (Cout, Cin, KH, KW))
+            sb = _sink(ctx.params[1], (Cout,)) if want_b else None
+            direct = sw is not None and (sb is not None or not want_b)     # both into the flat gradient buffer, or neither
+            gw = sw if direct else torch.empty(Cout, Cin, KH, KW, device=dev, dtype=torch.float32)
+            gb = (sb if direct else torch.empty(Cout, device=dev, dtype=torch.float32)) if want_b else None
             ws = torch.empty(L.load().e2e_conv2d_wgrad_workspace_floats(B, Ho, Wo, Cin, Cout, KH, KW, 1 if gb is not None else 0),
                              device=dev, dtype=torch.float32)
             L.call("e2e_conv2d_bwd_weight", L.ptr(dZ), L.ptr(src0), L.ptr(src1), C1, up, L.ptr(gw), L.ptr(gb), L.ptr(ws), B, Hs, Ws, Cin,
-                   Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, 0, isub, imul, st)
+                   Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, 1 if direct else 0, isub, imul, st)
+            if direct:
+                gw = gb = None
         return g0, g1, gw, gb, None, None, d_res, None, None, None, None, None, None, None, None
 
 

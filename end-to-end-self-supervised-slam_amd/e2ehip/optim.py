@@ -33,6 +33,7 @@ class FlatParams:
     def bind_grads(self):
         for p, o in zip(self.params, self.offsets):
             p.grad = self.grad[o:o + p.numel()].view_as(p)
+            p._e2e_grad_sink = p.grad              # conv backward may accumulate straight into it (conv.direct_weight_grads)
 
     def zero_grad(self):
         self.grad.zero_()

@@ -27,6 +27,7 @@ if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 
 from depth_estimation.networks import DispResNet_Indoor  # noqa: E402
+from e2ehip import conv as e2e_conv  # noqa: E402
 from e2ehip import dist as edist  # noqa: E402
 from e2ehip import ops  # noqa: E402
 from e2ehip.fused import LossGradPlan  # noqa: E402
@@ -177,7 +178,8 @@ class SLAM:
                 l3 = self.compute_3d_loss(d_tgt, K, poses[:, 1], T)
                 roots.append(l3 * a.LOSS.three3d_loss_weight)
                 grads.append(None)
-            torch.autograd.backward(roots, grads)
+            with e2e_conv.direct_weight_grads():      # weight gradients accumulate straight into FusedAdam's flat bucket
+                torch.autograd.backward(roots, grads)
             self._exchange_gradients()
             self.optimizer.step()
             if a.DEBUG.print_metrics:
