@@ -27,7 +27,10 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s 
 # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, KiB -> bytes;
 # profiles/r01_final_summaries.md).  The kernel loads 4- and 12-byte items, a pattern for which gfx950's FETCH_SIZE
 # halving (seen on 16-B/lane streams) is not calibrated, so the counters are taken at face value.
-TRAFFIC_NOTE = {(False, 1): (11088 + 2475) * 1024}
+TRAFFIC_NOTE = {(False, 1): (11065 + 2438) * 1024}
+# Why the HBM fraction of this kernel is low: it is bound by VALU issue, not by bytes.  SQ_INSTS_VALU per launch (same PMC
+# runs) x 4 cycles per wave64 instruction / 1024 SIMDs, against the measured launch duration at the ~2.3 GHz the counters show.
+VALU_NOTE = {(False, 1): {"wave_instructions": 3520800, "issue_cycles_per_simd": 3520800 * 4 // 1024, "clock_ghz": 2.3}}
 
 
 def cpu_baseline(H, W, budget_s=12.0):
@@ -245,6 +248,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_NOTE.get((a.split, B), None),
                          "launch_ms": launch_ms, "algorithmic_bytes": alg},
         }
+        vn = VALU_NOTE.get((a.split, B))
+        if vn is not None:
+            out["roofline"]["valu_issue"] = dict(vn, frac_of_launch=vn["issue_cycles_per_simd"] / (launch_ms[dom] * 1e-3 * vn["clock_ghz"] * 1e9))
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W)
         print(json.dumps(out))
