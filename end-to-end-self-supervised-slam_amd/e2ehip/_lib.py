@@ -67,6 +67,13 @@ SIGNATURES = {
     "e2e_mean_diff_bwd": [c_fp, c_fp, c_fp, c_i64, c_int, c_fp, c_fp],
     "e2e_depth_metrics": [c_fp, c_fp, c_i64, c_int, c_fp, c_fp, c_fp],
     "e2e_adam_step": [c_fp, c_fp, c_fp, c_fp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_fp],
+    "e2e_aux_workspace_floats": [],
+    "e2e_smoothness_lossgrad": [c_fp, c_fp, Strides, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
+    "e2e_geometric_consistency_lossgrad": [c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "e2e_masked_l1_lossgrad": [c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_fp],
+    "e2e_min_reprojection_lossgrad": [c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
+    "e2e_disp_blend_fwd": [c_fp, c_int, c_int, c_fp, c_fp],
+    "e2e_disp_blend_bwd": [c_fp, c_int, c_int, c_fp, c_fp],
     "e2e_conv_weight_layouts": [c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_int, c_fp],
     "e2e_conv_weight_layouts_batched": [c_fp, c_int, c_fp],
     "e2e_conv2d_fwd": [c_fp, c_fp, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp] + [c_int] * 11 + [c_f32, c_f32, c_fp, c_fp],
@@ -87,7 +94,7 @@ _RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats"
             "e2e_knn1_workspace_bytes": c_i64, "e2e_median_workspace_bytes": c_i64,
             "e2e_depth_scale_workspace_bytes": c_i64, "e2e_reduce_workspace_floats": c_i64,
             "e2e_conv2d_wgrad_workspace_floats": c_i64, "e2e_conv2d_splitk_workspace_floats": c_i64,
-            "e2e_head_workspace_floats": c_i64, "e2e_icp_workspace_bytes": c_i64}
+            "e2e_head_workspace_floats": c_i64, "e2e_icp_workspace_bytes": c_i64, "e2e_aux_workspace_floats": c_i64}
 
 _lib = None
 

@@ -473,3 +473,144 @@ def depth_metrics(gt, pred, mask_zero_gt):
     ws = torch.empty(L.load().e2e_reduce_workspace_floats(), device=gt.device, dtype=torch.float32)
     L.call("e2e_depth_metrics", L.ptr(gt), L.ptr(pred), gt.numel(), int(bool(mask_zero_gt)), L.ptr(out), L.ptr(ws), L.stream())
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# off-by-default losses (csrc/aux_losses.hip): each Function computes the loss AND the gradient for a unit upstream
+# gradient in its forward launch; backward only scales the stored gradient by the incoming scalar.
+# ---------------------------------------------------------------------------------------------------------------------
+def _aux_ws(dev):
+    return torch.empty(L.load().e2e_aux_workspace_floats(), device=dev, dtype=torch.float32)
+
+
+class _Smoothness(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, img):
+        d = L.dev(disp, "disp").contiguous()
+        im = L.dev(img, "img")
+        B, C, H, W = im.shape
+        if tuple(d.shape) != (B, 1, H, W):
+            raise ValueError(f"disp {tuple(d.shape)} does not match img {tuple(im.shape)}")
+        out = torch.empty(2, device=d.device, dtype=torch.float32)
+        g = torch.empty_like(d) if ctx.needs_input_grad[0] else None
+        L.call("e2e_smoothness_lossgrad", L.ptr(d), L.ptr(im), L.strides4(im), B, C, H, W, L.ptr(out), L.ptr(g), L.ptr(_aux_ws(d.device)), L.stream())
+        ctx.save_for_backward(g)
+        return out[0] + out[1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        return (g * go if g is not None else None), None
+
+
+def smoothness(disp, img):
+    """loss/losses.py:119-132: mean_x(|dx disp| exp(-mean_c |dx img|)) + mean_y(...); gradient w.r.t. disp only."""
+    return _Smoothness.apply(disp, img)
+
+
+class _GeomConsistency(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, wd, idp, mask):
+        a, b = L.dev(wd, "warped_depth").contiguous(), L.dev(idp, "interpolated_depth").contiguous()
+        if a.shape != b.shape:
+            raise ValueError("warped / interpolated depth shapes differ")
+        m = L.dev(mask, "valid_mask").expand_as(a).to(torch.float32).contiguous()
+        stats = torch.empty(3, device=a.device, dtype=torch.float32)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        ga = torch.empty_like(a) if need else None
+        gb = torch.empty_like(a) if need else None
+        L.call("e2e_geometric_consistency_lossgrad", L.ptr(a), L.ptr(b), L.ptr(m), a.numel(), L.ptr(stats), L.ptr(ga), L.ptr(gb),
+               L.ptr(_aux_ws(a.device)), L.stream())
+        ctx.save_for_backward(ga, gb)
+        return stats[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        ga, gb = ctx.saved_tensors
+        return (ga * go if ga is not None else None), (gb * go if gb is not None else None), None
+
+
+def geometric_consistency(warped_depth, interpolated_depth, valid_mask):
+    """loss/losses.py:84-95; the `mask.sum() > 10000` gate is evaluated on the device (no host sync)."""
+    return _GeomConsistency.apply(warped_depth, interpolated_depth, valid_mask)
+
+
+class _MaskedL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, mask):
+        p = L.dev(pred, "prediction").squeeze().contiguous()
+        g = L.dev(gt, "sparse_groundtruth").squeeze().to(torch.float32).contiguous()
+        m = L.dev(mask, "sparse_mask").squeeze().to(torch.float32).contiguous()
+        if not (p.shape == g.shape == m.shape):
+            raise ValueError("prediction / ground truth / mask shapes differ after squeeze()")
+        out = torch.empty(1, device=p.device, dtype=torch.float32)
+        gp = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        L.call("e2e_masked_l1_lossgrad", L.ptr(p), L.ptr(g), L.ptr(m), p.numel(), L.ptr(out), L.ptr(gp), L.ptr(_aux_ws(p.device)), L.stream())
+        ctx.save_for_backward(gp)
+        ctx.shape = pred.shape
+        return out.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        (gp,) = ctx.saved_tensors
+        return ((gp * go).reshape(ctx.shape) if gp is not None else None), None, None
+
+
+def masked_l1(prediction, sparse_groundtruth, sparse_mask):
+    """loss/losses.py:151-160 depth_gt_loss."""
+    return _MaskedL1.apply(prediction, sparse_groundtruth, sparse_mask)
+
+
+class _MinReprojection(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, errors):
+        e = L.dev(errors, "errors").contiguous()
+        B, C, H, W = e.shape
+        out = torch.empty(1, device=e.device, dtype=torch.float32)
+        ge = torch.empty_like(e) if ctx.needs_input_grad[0] else None
+        L.call("e2e_min_reprojection_lossgrad", L.ptr(e), B, C, H, W, L.ptr(out), L.ptr(ge), L.ptr(_aux_ws(e.device)), L.stream())
+        ctx.save_for_backward(ge)
+        return out.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        (ge,) = ctx.saved_tensors
+        return ge * go if ge is not None else None
+
+
+def min_reprojection(errors):
+    """train_depth.py:657-661: torch.min over the stacked per-source (and identity) error maps, then the mean."""
+    if errors.dim() != 4:
+        raise ValueError("errors must be (B, C, H, W)")
+    return _MinReprojection.apply(errors)
+
+
+class _DispBlend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pair):
+        d = L.dev(pair, "disp pair").contiguous()
+        if d.dim() != 4 or d.shape[0] != 2 or d.shape[1] != 1:
+            raise ValueError("process_disparity expects the (2,1,H,W) disparities of [img, flip(img)]")
+        H, W = d.shape[2], d.shape[3]
+        out = torch.empty(1, 1, H, W, device=d.device, dtype=torch.float32)
+        L.call("e2e_disp_blend_fwd", L.ptr(d), H, W, L.ptr(out), L.stream())
+        ctx.hw = (H, W)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        H, W = ctx.hw
+        g = go.contiguous()
+        gd = torch.empty(2, 1, H, W, device=g.device, dtype=torch.float32)
+        L.call("e2e_disp_blend_bwd", L.ptr(g), H, W, L.ptr(gd), L.stream())
+        return gd
+
+
+def process_disparity(disp_pair):
+    """train_depth.py:224-237 (dual-disparity post-processing)."""
+    return _DispBlend.apply(disp_pair)

@@ -42,13 +42,10 @@ def color_points_loss(gt_pointcloud_color, noisy_pointcloud_color, indexes):
 
 
 def geometric_consistency_loss(outputs, frame, device):
-    """reference: losses.py:84-95 (keeps the host-side `mask.sum() > 10000` decision)."""
-    wd, idp = outputs[("warped_depth", frame)], outputs[("interpolated_depth", frame)]
-    diff = ((wd - idp).abs() / (wd + idp)).clamp(0, 1)
-    mask = outputs[("valid_mask", frame)].expand_as(diff)
-    if mask.sum() > 10000:
-        return (diff * mask).sum() / mask.sum()
-    return torch.tensor(0).float().to(device)
+    """reference: losses.py:84-95.  One fused pass (csrc/aux_losses.hip); the reference's host-side
+    `mask.sum() > 10000` decision is taken on the device, so there is no synchronisation."""
+    return ops.geometric_consistency(outputs[("warped_depth", frame)], outputs[("interpolated_depth", frame)],
+                                     outputs[("valid_mask", frame)])
 
 
 def photometric_loss(ssim, prediction, target):
@@ -60,12 +57,8 @@ def photometric_loss(ssim, prediction, target):
 
 
 def disparity_smoothness_loss(disp, img):
-    """reference: losses.py:119-132 (off by default: config.yaml:47)."""
-    gdx = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
-    gdy = torch.abs(disp[:, :, :-1, :] - disp[:, :, 1:, :])
-    gix = torch.mean(torch.abs(img[:, :, :, :-1] - img[:, :, :, 1:]), 1, keepdim=True)
-    giy = torch.mean(torch.abs(img[:, :, :-1, :] - img[:, :, 1:, :]), 1, keepdim=True)
-    return (gdx * torch.exp(-gix)).mean() + (gdy * torch.exp(-giy)).mean()
+    """reference: losses.py:119-132 (off by default: config.yaml:47); loss and d/d(disp) in one kernel."""
+    return ops.smoothness(disp, img)
 
 
 def depth_reguralizer(initial_depth, refined_depth, loss_func):
@@ -79,7 +72,18 @@ def depth_reguralizer(initial_depth, refined_depth, loss_func):
 
 def depth_gt_loss(prediction, sparse_groundtruth, sparse_mask):
     """reference: losses.py:151-160."""
-    return torch.mean(torch.abs(prediction.squeeze() * sparse_mask.squeeze() - sparse_groundtruth.squeeze()))
+    return ops.masked_l1(prediction, sparse_groundtruth, sparse_mask)
+
+
+def min_reprojection_loss(error_maps):
+    """train_depth.py:657-661: minimum over the stacked per-source (and auto-masking identity) photometric maps,
+    then the mean.  error_maps (B, C, H, W)."""
+    return ops.min_reprojection(error_maps)
+
+
+def process_disparity(disp_pair):
+    """train_depth.py:224-237: blend of the disparity of an image and of its flipped copy, (2,1,H,W) -> (1,1,H,W)."""
+    return ops.process_disparity(disp_pair)
 
 
 @torch.no_grad()

@@ -351,6 +351,42 @@ int e2e_icp_normal_equations(const float* src, const float* tgt, const float* tg
                              const long long* idx, const float* dists, float dist_thresh, int64_t n,
                              double* out29, void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Off-by-default losses: loss value(s) AND the gradient for a unit upstream  */
+/* gradient in one pass each; workspace: e2e_aux_workspace_floats() floats.                      */
+/* ------------------------------------------------------------------------------------------ */
+int64_t e2e_aux_workspace_floats(void);
+
+/* loss/losses.py:119-132 disparity_smoothness_loss.  disp (B,1,H,W) contiguous, img (B,C,H,W)
+ * through element strides.  loss_out[0] = x term, loss_out[1] = y term (the loss is their sum);
+ * g_disp (B,1,H,W) = d(sum)/d(disp) or NULL. */
+int e2e_smoothness_lossgrad(const float* disp, const float* img, e2e_strides img_strides, int B, int C,
+                            int H, int W, float* loss_out, float* g_disp, float* workspace,
+                            void* stream);
+
+/* loss/losses.py:84-95 geometric_consistency_loss on n elements (mask as float, already expanded).
+ * stats_out3 = {loss, sum(mask), gradient normaliser}; the `sum(mask) > 10000` gate is evaluated
+ * on the device (loss and gradients are 0 when it is closed).  g_* both NULL or both given. */
+int e2e_geometric_consistency_lossgrad(const float* warped_depth, const float* interpolated_depth,
+                                       const float* mask, int64_t n, float* stats_out3,
+                                       float* g_warped, float* g_interpolated, float* workspace,
+                                       void* stream);
+
+/* loss/losses.py:151-160 depth_gt_loss: mean |prediction * mask - sparse_gt| over n elements. */
+int e2e_masked_l1_lossgrad(const float* prediction, const float* sparse_gt, const float* sparse_mask,
+                           int64_t n, float* loss_out, float* g_prediction, float* workspace,
+                           void* stream);
+
+/* train_depth.py:657-661: mean over (b,y,x) of min over the C stacked error maps (B,C,H,W); the
+ * gradient goes to the first minimal channel. */
+int e2e_min_reprojection_lossgrad(const float* errors, int B, int C, int H, int W, float* loss_out,
+                                  float* g_errors, float* workspace, void* stream);
+
+/* train_depth.py:224-237 process_disparity: disp_pair (2,1,H,W) = net(img), net(flip(img)) ->
+ * out (1,1,H,W); bwd: g_out (H,W) -> g_disp_pair (2,1,H,W). */
+int e2e_disp_blend_fwd(const float* disp_pair, int H, int W, float* out, void* stream);
+int e2e_disp_blend_bwd(const float* g_out, int H, int W, float* g_disp_pair, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

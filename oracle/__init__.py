@@ -10,6 +10,8 @@ Parity status (see DESIGN.md "Oracle"):
     tests/golden/make_golden.py captured from the reference's own files
     (depth_estimation/view_synthesis.py, loss/losses.py, utils/training_utils.py,
     depth_estimation/networks.py) loaded by path in the build container.
+  * warp_loss.py::min_reprojection / process_disparity restate train_depth.py:224-237,657-661 from
+    the text of that file (its import block needs gradslam / cv2 / tensorboardX) -- PARITY UNPINNED.
   * pointfusion.py, knn.py (gradslam / chamferdist semantics) and the ResNet-18 body of
     depthnet.py (torchvision) -- PARITY UNPINNED: those packages are absent from
     /root/reference and are not installed (README.md:5-33 gives no version pins); the

@@ -139,6 +139,24 @@ def depth_gt(prediction, sparse_gt, sparse_mask):
     return torch.mean(torch.abs(prediction.squeeze() * sparse_mask.squeeze() - sparse_gt.squeeze()))
 
 
+def min_reprojection(error_maps):
+    """reference: train_depth.py:657-661 (`optimize, indexs = torch.min(photmetric, dim=1); optimize.mean()`)."""
+    return torch.min(error_maps, dim=1)[0].mean()
+
+
+def process_disparity(disp_pair):
+    """reference: train_depth.py:224-237.  `l_mesh, _ = torch.meshgrid(linspace(0,1,h), linspace(0,1,w))` varies along
+    the ROWS (ij indexing), so the flipped mask equals the mask; the expression is kept term by term."""
+    left = disp_pair[:1]
+    right = torch.flip(disp_pair[1:], [3])
+    middle = 0.5 * (left + right)
+    h, w = left.shape[2], left.shape[3]
+    l_mesh, _ = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij")
+    l_mask = (1.0 - torch.clip(20 * (l_mesh - 0.05), 0, 1)).unsqueeze(0).unsqueeze(0)
+    r_mask = torch.flip(l_mask, [3])
+    return r_mask * left + l_mask * right + (1.0 - l_mask - r_mask) * middle
+
+
 def depth_errors(gt, pred):
     """reference: losses.py:183-201 -> abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3."""
     thresh = torch.max(gt / pred, pred / gt)
