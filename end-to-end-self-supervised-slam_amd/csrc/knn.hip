@@ -488,32 +488,77 @@ int64_t e2e_knn1_workspace_bytes(int64_t n1, int64_t n2) {
     return brute > grid ? brute : grid;
 }
 
-static int knn1_grid(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists, long long* idx, void* workspace, hipStream_t st) {
-    const int64_t nc = grid_cells_cap(n2), nscan = nc + 1;
-    const int nb = (int)((nscan + SCAN_BLOCK - 1) / SCAN_BLOCK);
+struct GridWs {
+    GridInfo* gi;
+    unsigned int *counts, *starts, *fill, *bsum, *bbpart, *cell_of, *unresolved;
+    float4* sorted;
+    int64_t nc;
+    int nb;
+};
+
+// carve the workspace: `nq` = number of query slots reserved for the unresolved list
+static GridWs grid_ws(void* workspace, int64_t nq, int64_t n2) {
+    GridWs g;
+    g.nc = grid_cells_cap(n2);
+    g.nb = (int)((g.nc + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK);
     char* w = (char*)workspace;
-    GridInfo* gi = (GridInfo*)w; w += 256;
-    unsigned int* counts = (unsigned int*)w; w += 4 * (nc + 1);
-    unsigned int* starts = (unsigned int*)w; w += 4 * (nc + 1);
-    unsigned int* fill = (unsigned int*)w; w += 4 * nc;
-    unsigned int* bsum = (unsigned int*)w; w += 4 * (nb + 1);
-    unsigned int* bbpart = (unsigned int*)w; w += 4 * 6 * BBOX_BLOCKS;
-    unsigned int* cell_of = (unsigned int*)w; w += 4 * n2;
-    unsigned int* unresolved = (unsigned int*)w; w += 4 * n1;
+    g.gi = (GridInfo*)w; w += 256;
+    g.counts = (unsigned int*)w; w += 4 * (g.nc + 1);
+    g.starts = (unsigned int*)w; w += 4 * (g.nc + 1);
+    g.fill = (unsigned int*)w; w += 4 * g.nc;
+    g.bsum = (unsigned int*)w; w += 4 * (g.nb + 1);
+    g.bbpart = (unsigned int*)w; w += 4 * 6 * BBOX_BLOCKS;
+    g.cell_of = (unsigned int*)w; w += 4 * n2;
+    g.unresolved = (unsigned int*)w; w += 4 * nq;
     w = (char*)(((uintptr_t)w + 63) & ~(uintptr_t)63);
-    float4* sorted = (float4*)w;
+    g.sorted = (float4*)w;
+    return g;
+}
+
+__global__ void k_grid_reset_unresolved(GridInfo* gi) { gi->n_unresolved = 0; }
+
+static void grid_build(const float* p2, int64_t n2, const GridWs& g, hipStream_t st) {
+    const int64_t nscan = g.nc + 1;
     const int gp = (int)((n2 + KT - 1) / KT > 2048 ? 2048 : (n2 + KT - 1) / KT);
-    hipLaunchKernelGGL(k_grid_init, dim3(2048), dim3(256), 0, st, gi, counts, fill, nc);
+    hipLaunchKernelGGL(k_grid_init, dim3(2048), dim3(256), 0, st, g.gi, g.counts, g.fill, g.nc);
     const int bb_blocks = gp > BBOX_BLOCKS ? BBOX_BLOCKS : gp;
-    hipLaunchKernelGGL(k_grid_bbox, dim3(bb_blocks), dim3(KT), 0, st, p2, n2, bbpart);
-    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(BBOX_BLOCKS), 0, st, gi, bbpart, bb_blocks, grid_max_for(n2));
-    hipLaunchKernelGGL(k_grid_count, dim3(gp), dim3(KT), 0, st, p2, n2, gi, cell_of, counts);
-    hipLaunchKernelGGL(k_scan_blocksum, dim3(nb), dim3(KT), 0, st, counts, nscan, bsum);
-    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, bsum, nb);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(KT), 0, st, counts, nscan, bsum, starts);
-    hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(KT), 0, st, p2, n2, cell_of, starts, fill, sorted);
-    hipLaunchKernelGGL(k_grid_query, dim3((unsigned)((n1 + KT - 1) / KT)), dim3(KT), 0, st, p1, n1, gi, starts, sorted, dists, idx, unresolved);
-    hipLaunchKernelGGL(k_knn1_rest, dim3(1024), dim3(KT), 0, st, p1, gi, starts, sorted, unresolved, dists, idx);
+    hipLaunchKernelGGL(k_grid_bbox, dim3(bb_blocks), dim3(KT), 0, st, p2, n2, g.bbpart);
+    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(BBOX_BLOCKS), 0, st, g.gi, g.bbpart, bb_blocks, grid_max_for(n2));
+    hipLaunchKernelGGL(k_grid_count, dim3(gp), dim3(KT), 0, st, p2, n2, g.gi, g.cell_of, g.counts);
+    hipLaunchKernelGGL(k_scan_blocksum, dim3(g.nb), dim3(KT), 0, st, g.counts, nscan, g.bsum);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, g.bsum, g.nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3(g.nb), dim3(KT), 0, st, g.counts, nscan, g.bsum, g.starts);
+    hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(KT), 0, st, p2, n2, g.cell_of, g.starts, g.fill, g.sorted);
+}
+
+static void grid_query(const float* p1, int64_t n1, const GridWs& g, float* dists, long long* idx, hipStream_t st) {
+    hipLaunchKernelGGL(k_grid_query, dim3((unsigned)((n1 + KT - 1) / KT)), dim3(KT), 0, st, p1, n1, g.gi, g.starts, g.sorted, dists, idx, g.unresolved);
+    hipLaunchKernelGGL(k_knn1_rest, dim3(1024), dim3(KT), 0, st, p1, g.gi, g.starts, g.sorted, g.unresolved, dists, idx);
+}
+
+static int knn1_grid(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists, long long* idx, void* workspace, hipStream_t st) {
+    const GridWs g = grid_ws(workspace, n1, n2);
+    grid_build(p2, n2, g, st);
+    grid_query(p1, n1, g, dists, idx, st);
+    return E2E_OK;
+}
+
+/* Persistent index: build once for a reference set, query many times (ICP iterations, the refinement steps of one
+ * keyframe).  The index occupies e2e_knn1_workspace_bytes(max_queries, n2) bytes owned by the caller. */
+int e2e_knn1_index_build(const float* p2, int64_t n2, int64_t max_queries, void* index, void* stream) {
+    E2E_REQUIRE(p2 && index && n2 > 0 && n2 < 0xFFFFFFFFll && max_queries > 0 && max_queries < 0xFFFFFFFFll, E2E_ERR_ARG, "e2e_knn1_index_build: bad argument");
+    grid_build(p2, n2, grid_ws(index, max_queries, n2), (hipStream_t)stream);
+    E2E_LAUNCH_CHECK("e2e_knn1_index_build");
+    return E2E_OK;
+}
+
+int e2e_knn1_index_query(const float* p1, int64_t n1, int64_t n2, int64_t max_queries, void* index, float* dists, long long* idx, void* stream) {
+    E2E_REQUIRE(p1 && index && dists && idx && n1 > 0 && n1 <= max_queries && n2 > 0, E2E_ERR_ARG,
+                "e2e_knn1_index_query: bad argument (n1=%lld must not exceed the max_queries=%lld the index was built for)", (long long)n1, (long long)max_queries);
+    const GridWs g = grid_ws(index, max_queries, n2);
+    hipLaunchKernelGGL(k_grid_reset_unresolved, dim3(1), dim3(1), 0, (hipStream_t)stream, g.gi);
+    grid_query(p1, n1, g, dists, idx, (hipStream_t)stream);
+    E2E_LAUNCH_CHECK("e2e_knn1_index_query");
     return E2E_OK;
 }
 

@@ -56,6 +56,8 @@ SIGNATURES = {
     "e2e_pf_fuse_append": [c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp],
     "e2e_knn1_workspace_bytes": [c_i64, c_i64],
     "e2e_knn1_fwd": [c_fp, c_i64, c_fp, c_i64, c_fp, c_fp, c_fp, c_int, c_fp],
+    "e2e_knn1_index_build": [c_fp, c_i64, c_i64, c_fp, c_fp],
+    "e2e_knn1_index_query": [c_fp, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp],
     "e2e_knn1_bwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_fp, c_fp],
     "e2e_median_workspace_bytes": [],
     "e2e_median_lower": [c_fp, c_i64, c_fp, c_fp, c_fp],

@@ -27,6 +27,16 @@ class FusionMap:
         self._count = torch.zeros(1, device=self.device, dtype=torch.int64)
         self._assoc_M = None
 
+    # -- nearest-neighbour index over the live points (rebuilt lazily after every map change) ------------------------
+    def knn_index(self, max_queries=None):
+        from .ops import KnnIndex
+        mq = int(max_queries or self.H * self.W)
+        idx = getattr(self, "_knn", None)
+        if idx is None or idx[0] != self.M or idx[1].max_queries < mq:
+            idx = (self.M, KnnIndex(self.points[: self.M], mq))
+            self._knn = idx
+        return idx[1]
+
     # -- views of the live part -------------------------------------------------------------------
     def live(self):
         M = self.M
@@ -39,6 +49,7 @@ class FusionMap:
             raise ValueError("map state exceeds capacity")
         self.points[:M], self.normals[:M], self.colors[:M], self.ccounts[:M] = points, normals, colors, ccounts
         self.M = M
+        self._knn = None
 
     # -- one map step --------------------------------------------------------------------------------
     def frame_maps(self, depth, K, pose):
@@ -69,6 +80,7 @@ class FusionMap:
         if new_m > self.cap:
             raise RuntimeError(f"PointFusion map capacity exceeded ({new_m} > {self.cap}); size it for the sequence")
         self.M = new_m
+        self._knn = None                                    # fused points moved, new ones were appended
 
     def step(self, rgb, depth, K, pose):
         """PointFusion.step with a known pose (update_map_fusion).  rgb (H,W,3), depth (H,W)."""

@@ -39,8 +39,8 @@ def _unpack(v):
     return AtA, v[21:27], int(round(v[27])), float(v[28])
 
 
-def _reduce(cur, tgt, tgt_n, dist_thresh, out, ws):
-    d, idx = ops.knn1(cur, tgt)
+def _reduce(cur, tgt, tgt_n, dist_thresh, out, ws, index=None):
+    d, idx = ops.knn1(cur, index if index is not None else tgt)
     L.call("e2e_icp_normal_equations", L.ptr(cur), L.ptr(tgt), L.ptr(tgt_n), L.ptr(idx), L.ptr(d),
            -1.0 if dist_thresh is None else float(dist_thresh), cur.shape[0], L.ptr(out), L.ptr(ws), L.stream())
     return _unpack(out.cpu().numpy())
@@ -57,16 +57,17 @@ def point_to_plane_icp(src, tgt, tgt_n, numiters=20, damp=1e-8, dist_thresh=None
     T = np.eye(4)
     lam = float(damp)
     trace = []
+    index = ops.KnnIndex(tgt, src.shape[0])               # the target cloud is fixed: one grid for all iterations
     for _ in range(numiters):
         cur = ops.transform_points(src, torch.from_numpy(T).float().to(dev))
-        AtA, Atb, cnt, err = _reduce(cur, tgt, tgt_n, dist_thresh, out, ws)
+        AtA, Atb, cnt, err = _reduce(cur, tgt, tgt_n, dist_thresh, out, ws, index)
         if cnt < 6:
             break
         xi = np.linalg.solve(AtA + lam * np.eye(6), Atb)
         step = se3_exp(xi)
         if mode == "gradicp":
             nxt = ops.transform_points(cur, torch.from_numpy(step).float().to(dev))
-            _, _, cnt2, err2 = _reduce(nxt, tgt, tgt_n, dist_thresh, out, ws)
+            _, _, cnt2, err2 = _reduce(nxt, tgt, tgt_n, dist_thresh, out, ws, index)
             delta = (err2 / max(cnt2, 1)) - (err / max(cnt, 1))
             lam = lam * (1.0 / lambda_max + (lambda_max - 1.0 / lambda_max) / (1.0 + B * np.exp(-B2 * nu * delta)))
             step = se3_exp(xi / (1.0 + np.exp(np.clip(nu * delta, -60, 60))))

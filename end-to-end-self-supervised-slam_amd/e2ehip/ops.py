@@ -373,10 +373,52 @@ class _Knn1(torch.autograd.Function):
         return gp, None, None
 
 
+class KnnIndex:
+    """Uniform-grid index over a fixed reference cloud: built once, queried many times with results identical to
+    knn1(p1, ref).  The reference tensor must not change while the index is in use (FusionMap drops its index whenever
+    the map is updated)."""
+
+    def __init__(self, ref, max_queries):
+        ref = L.dev(ref, "ref")
+        if ref.dim() != 2 or ref.shape[1] != 3 or ref.shape[0] == 0 or ref.requires_grad:
+            raise ValueError("KnnIndex: reference cloud must be a detached, non-empty (P,3) tensor")
+        self.ref = ref.contiguous()
+        self.n2, self.max_queries = self.ref.shape[0], int(max_queries)
+        self.ws = torch.empty(L.load().e2e_knn1_workspace_bytes(self.max_queries, self.n2), device=ref.device, dtype=torch.uint8)
+        L.call("e2e_knn1_index_build", L.ptr(self.ref), self.n2, self.max_queries, L.ptr(self.ws), L.stream())
+
+
+class _Knn1Indexed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p1, index):
+        a = L.dev(p1, "p1").contiguous()
+        n1 = a.shape[0]
+        d = torch.empty(n1, device=a.device, dtype=torch.float32)
+        idx = torch.empty(n1, device=a.device, dtype=torch.int64)
+        L.call("e2e_knn1_index_query", L.ptr(a), n1, index.n2, index.max_queries, L.ptr(index.ws), L.ptr(d), L.ptr(idx), L.stream())
+        ctx.save_for_backward(a, index.ref, idx)
+        ctx.mark_non_differentiable(idx)
+        return d, idx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gd, _gi):
+        a, b, idx = ctx.saved_tensors
+        gp = torch.empty_like(a)
+        L.call("e2e_knn1_bwd", L.ptr(gd.contiguous()), L.ptr(a), L.ptr(b), L.ptr(idx), a.shape[0], L.ptr(gp), L.stream())
+        return gp, None
+
+
 def knn1(p1, p2, algorithm="auto"):
-    """algorithm: "auto" | "brute" | "grid" (identical results).  K=1 nearest neighbour of every row of p1 (P1,3) among p2 (P2,3): (squared dists (P1,), idx (P1,) int64).
+    """p2 may be a KnnIndex (prebuilt grid over the reference cloud).  algorithm: "auto" | "brute" | "grid" (identical results).  K=1 nearest neighbour of every row of p1 (P1,3) among p2 (P2,3): (squared dists (P1,), idx (P1,) int64).
     Differentiable wrt p1 (d/dp1 = 2 g (p1 - p2[idx])); p2 is treated as data (the reference detaches it,
     online_adaption.py:643)."""
+    if isinstance(p2, KnnIndex):
+        if p1.dim() != 2 or p1.shape[1] != 3 or p1.shape[0] == 0:
+            raise ValueError(f"p1: expected non-empty (P,3), got {tuple(p1.shape)}")
+        if p1.shape[0] > p2.max_queries:
+            raise ValueError(f"knn1: {p1.shape[0]} queries exceed the {p2.max_queries} the index was built for")
+        return _Knn1Indexed.apply(p1, p2)
     for n, t in (("p1", p1), ("p2", p2)):
         if t.dim() != 2 or t.shape[1] != 3:
             raise ValueError(f"{n}: expected (P,3), got {tuple(t.shape)}")

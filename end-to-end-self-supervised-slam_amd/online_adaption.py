@@ -202,7 +202,7 @@ class SLAM:
         maps = ops.vertex_normal_maps(d_tgt.reshape(1, self.H, self.W), K, pose_tgt, self.map.sigma)
         cloud = ops.select_rows(maps["Vg"][0].reshape(-1, 3), maps["valid"][0].reshape(-1))
         moved = ops.transform_points(cloud, T[0])
-        d, _ = ops.knn1(moved, self.map.points[: self.map.M])
+        d, _ = ops.knn1(moved, self.map.knn_index(self.H * self.W))    # one grid build per keyframe, three queries
         return d.mean()
 
     def _exchange_gradients(self):

@@ -226,6 +226,13 @@ int e2e_knn1_fwd(const float* p1, int64_t n1, const float* p2, int64_t n2, float
 int e2e_knn1_bwd(const float* g_dists, const float* p1, const float* p2, const long long* idx,
                  int64_t n1, float* g_p1, void* stream);
 
+/* Persistent index over one reference set: build once, query many times (ICP iterations, the
+ * refinement steps of one keyframe all search the same map).  `index`: caller-owned buffer of
+ * e2e_knn1_workspace_bytes(max_queries, n2) bytes; results are identical to e2e_knn1_fwd. */
+int e2e_knn1_index_build(const float* p2, int64_t n2, int64_t max_queries, void* index, void* stream);
+int e2e_knn1_index_query(const float* p1, int64_t n1, int64_t n2, int64_t max_queries, void* index,
+                         float* dists, long long* idx, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* disp -> depth, median scaling, regulariser, metrics, optimiser                                */
 /* ------------------------------------------------------------------------------------------ */

@@ -231,3 +231,23 @@ def test_knn_grid_equals_brute(case):
     db, ib = ops.knn1(q.to(DEV), ref.to(DEV), "brute")
     dg, ig = ops.knn1(q.to(DEV), ref.to(DEV), "grid")
     assert torch.equal(db, dg) and torch.equal(ib, ig)
+
+
+def test_knn_index_equals_one_shot_and_is_reusable():
+    """A prebuilt KnnIndex answers several query sets exactly like knn1(p1, ref) (brute force), gradients included."""
+    from e2ehip import ops
+    g = torch.Generator().manual_seed(77)
+    ref = torch.rand(70000, 3, generator=g)
+    ref[100:140] = ref[3]
+    index = ops.KnnIndex(ref.to(DEV), 9000)
+    for k, n1 in enumerate((9000, 1, 4096)):
+        q = (torch.rand(n1, 3, generator=g) * (1.0 + k)).to(DEV).requires_grad_(True)       # later sets reach outside the cloud
+        d, i = ops.knn1(q, index)
+        qb = q.detach().clone().requires_grad_(True)
+        db, ib = ops.knn1(qb, ref.to(DEV), "brute")
+        assert torch.equal(d, db) and torch.equal(i, ib)
+        d.sum().backward()
+        db.sum().backward()
+        assert torch.equal(q.grad, qb.grad)
+    with pytest.raises(ValueError):
+        ops.knn1(torch.rand(9001, 3, device=DEV), index)
