@@ -490,6 +490,154 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm(WgradArgs a) {
     }
 }
 
+// VEC-4 backward-weight with the lean loader of k_conv_gemm: buffer resources + 32-bit offsets (structural zeros are
+// out-of-range offsets), no integer divisions in the chunk loop, CB pixels per chunk.  A concat layer reads its two
+// sources through two resources: lanes of one load instruction span columns on both sides of the split, and a
+// resource is wave-uniform, so each slot issues one load per source with the foreign lanes out of range.
+template <int WM, int WN, int CB>
+__global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
+    constexpr int BM = 32 * WM, BN = 32 * WN, NT = 256;     // WM x WN = 4 waves, one 32x32 accumulator each
+    constexpr int A_CNT = CB * (BM / 4), B_CNT = CB * (BN / 4);
+    constexpr int A_PER = (A_CNT + NT - 1) / NT, B_PER = (B_CNT + NT - 1) / NT;
+    __shared__ float As[2][CB][BM];
+    __shared__ float Bs[2][CB][BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int m0 = blockIdx.y * BM, nn0 = blockIdx.x * BN;
+    const int64_t P = (int64_t)a.B * a.Ho * a.Wo;
+    const int64_t p0 = (int64_t)blockIdx.z * a.pix_per_slice;
+    const int64_t p1 = (p0 + a.pix_per_slice < P) ? p0 + a.pix_per_slice : P;
+    const int npix = (p1 > p0) ? (int)(p1 - p0) : 0;
+    const int nchunks = (npix + CB - 1) / CB;
+    const int sh = a.up >> 1;
+    const int Hl = a.Hs >> sh, Wl = a.Ws >> sh, C2 = a.Cin - a.C1;
+    const int Kconv = a.KH * a.KW * a.Cin;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, (int)(P * a.Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)((int64_t)a.B * Hl * Wl * a.C1 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0,
+                                                                         (int)(a.src1 ? (int64_t)a.B * a.Hs * a.Ws * C2 * 4 : 0), 0x00020000);
+    // which source do this workgroup's columns read?  0: src0 only, 1: src1 only (the tile lies inside one tap on one side
+    // of the concat split), 2: both (one load per source and slot)
+    int src_mode = 0;
+    if (a.src1 != nullptr) {
+        const int c_lo = min(nn0, Kconv - 1), c_hi = min(nn0 + BN - 1, Kconv - 1);
+        const int t_lo = c_lo / a.Cin, t_hi = c_hi / a.Cin;
+        const bool lo0 = (c_lo - t_lo * a.Cin) < a.C1, hi0 = (c_hi - t_hi * a.Cin) < a.C1;
+        src_mode = (t_lo == t_hi && lo0 == hi0) ? (lo0 ? 0 : 1) : 2;
+    }
+
+    // A (dZ) slots: row kr of the chunk, cout quad -- the chunk rides in soffset
+    int a_kr[A_PER];
+    unsigned a_off[A_PER];
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) {
+        const int idx = tid + j * NT;
+        a_kr[j] = idx / (BM / 4);
+        const int m = m0 + (idx - a_kr[j] * (BM / 4)) * 4;
+        a_off[j] = (idx < A_CNT && m < a.Cout) ? (unsigned)(a_kr[j] * a.Cout + m) * 4u : OOB;      // Cout % 4 == 0
+    }
+    // B (gathered input) slots: pixel row kr of the chunk, column quad -> (tap, ci) decoded once; the pixel advances by CB
+    int b_kr[B_PER], b_kh[B_PER], b_kw[B_PER], b_ci[B_PER], pb[B_PER], poh[B_PER], pow_[B_PER];
+    bool b_conv[B_PER], b_ones[B_PER], b_src0[B_PER];
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+        const int idx = tid + j * NT;
+        b_kr[j] = idx / (BN / 4);
+        const int col = nn0 + (idx - b_kr[j] * (BN / 4)) * 4;
+        b_conv[j] = idx < B_CNT && col < Kconv;
+        b_ones[j] = idx < B_CNT && a.has_bias && col == Kconv;
+        const int tap = b_conv[j] ? col / a.Cin : 0;
+        b_ci[j] = b_conv[j] ? col - tap * a.Cin : 0;
+        b_src0[j] = b_ci[j] < a.C1;
+        b_kh[j] = tap / a.KW;
+        b_kw[j] = tap - b_kh[j] * a.KW;
+        const int64_t p = p0 + b_kr[j];
+        const int hw = a.Ho * a.Wo;
+        pb[j] = (int)(p / hw);
+        const int r = (int)(p - (int64_t)pb[j] * hw);
+        poh[j] = r / a.Wo;
+        pow_[j] = r - poh[j] * a.Wo;
+    }
+    f4v areg[A_PER], breg[B_PER];
+    int ld_chunk = 0;
+    auto load_chunk = [&]() {
+        const int left = npix - ld_chunk * CB;               // pixels of the slice that remain from this chunk on
+        const int soffz = (int)((p0 + (int64_t)ld_chunk * CB) * a.Cout * 4);
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j)
+            areg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsz, (a_kr[j] < left) ? a_off[j] : OOB, soffz, 0));
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            int ys = poh[j] * a.stride + b_kh[j] - a.pad, xs = pow_[j] * a.stride + b_kw[j] - a.pad;
+            bool ok = b_conv[j] && b_kr[j] < left;
+            if (a.pad_mode == 1) { ys = reflect1(ys, a.Hs); xs = reflect1(xs, a.Ws); }
+            else ok = ok && ys >= 0 && ys < a.Hs && xs >= 0 && xs < a.Ws;
+            const unsigned o0 = (unsigned)(((pb[j] * Hl + (ys >> sh)) * Wl + (xs >> sh)) * a.C1 + b_ci[j]) * 4u;
+            const unsigned o1 = (unsigned)(((pb[j] * a.Hs + ys) * a.Ws + xs) * C2 + (b_ci[j] - a.C1)) * 4u;
+            f4v v;
+            if (src_mode == 0) {
+                v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? o0 : OOB, 0, 0));
+            } else if (src_mode == 1) {
+                v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs1, ok ? o1 : OOB, 0, 0));
+            } else {
+                v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs0, (ok && b_src0[j]) ? o0 : OOB, 0, 0));
+                const f4v v1 = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs1, (ok && !b_src0[j]) ? o1 : OOB, 0, 0));
+                v = b_src0[j] ? v : v1;
+            }
+            if (b_ones[j]) v = (f4v){(b_kr[j] < left) ? 1.f : 0.f, 0.f, 0.f, 0.f};   // ones column: dW[:, Kconv] = sum_p dZ = bias gradient
+            breg[j] = v;
+            pow_[j] += CB;                                   // advance this slot's pixel by one chunk (CB <= 2 * Wo in this network;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2)                   // four wraps cover Wo >= CB / 4)
+                if (pow_[j] >= a.Wo) { pow_[j] -= a.Wo; if (++poh[j] == a.Ho) { poh[j] = 0; ++pb[j]; } }
+        }
+        ++ld_chunk;
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            const int idx = tid + j * NT;
+            if (idx >= A_CNT) continue;
+            *(f4v*)&As[buf][a_kr[j]][(idx - a_kr[j] * (BM / 4)) * 4] = areg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int idx = tid + j * NT;
+            if (idx >= B_CNT) continue;
+            *(f4v*)&Bs[buf][b_kr[j]][(idx - b_kr[j] * (BN / 4)) * 4] = breg[j];
+        }
+    };
+    f16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (nchunks > 0) {
+        load_chunk();
+        store_chunk(0);
+    }
+    __syncthreads();
+    const int khalf = lane >> 5;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk();
+#pragma unroll
+        for (int kk = 0; kk < CB / 2; ++kk) {
+            const float av = As[buf][kk * 2 + khalf][wm * 32 + (lane & 31)];
+            const float bv = Bs[buf][kk * 2 + khalf][wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    float* slab = a.slabs + (int64_t)blockIdx.z * a.Mpad * a.Npad;
+    const int n = nn0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (m < a.Mpad && n < a.Npad) slab[(int64_t)m * a.Npad + n] = acc[r];
+    }
+}
+
 // fold groups of FOLD consecutive slabs into one (fixed order inside a group, groups stay in order): turns the serial
 // S-long sum of the final pass into a two-level tree with S/FOLD-fold more parallelism
 #define WG_FOLD 16
@@ -959,11 +1107,17 @@ int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1,
         if (S > maxS) S = maxS;
         if (S < 1) S = 1;
     }
-    a.pix_per_slice = ((P + S - 1) / S + CBK - 1) / CBK * CBK;
+    // lean VEC-4 kernel: 32 pixels per chunk; needs Cout % 4 == 0, 32-bit offsets and image rows of at least 8 pixels
+    const bool lean = vec == 4 && Cout % 4 == 0 && Wo >= 8 && (int64_t)B * Hs * Ws * Cin * 4 < (1ll << 31) && P * Cout * 4 < (1ll << 31);
+    const int cbp = lean ? 32 : CBK;
+    a.pix_per_slice = ((P + S - 1) / S + cbp - 1) / cbp * cbp;
     const int Sz = (int)((P + a.pix_per_slice - 1) / a.pix_per_slice);
     dim3 g((unsigned)(a.Npad / tn), (unsigned)(a.Mpad / tm), (unsigned)Sz);
     hipStream_t st = (hipStream_t)stream;
-    if (tm == 32) {
+    if (lean) {
+        if (tm == 32) hipLaunchKernelGGL((k_wgrad_gemm4<1, 4, 32>), g, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_wgrad_gemm4<2, 2, 32>), g, dim3(256), 0, st, a);
+    } else if (tm == 32) {
         if (vec == 4) hipLaunchKernelGGL((k_wgrad_gemm<1, 4, 4>), g, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_wgrad_gemm<1, 4, 1>), g, dim3(256), 0, st, a);
     } else {
