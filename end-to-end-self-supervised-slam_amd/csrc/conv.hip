@@ -703,20 +703,51 @@ __global__ __launch_bounds__(256) void k_weight_layouts(const float* __restrict_
 // table of 10 int64 per layer on the device: {w, w_fwd, w_bwd, Cout, Cin, KH, KW, ld_fwd, ld_bwd, reserved}
 __global__ __launch_bounds__(256) void k_weight_layouts_batched(const long long* __restrict__ desc) {
     const long long* d = desc + (int64_t)blockIdx.y * 10;
-    const float* w = (const float*)d[0];
-    float* wf = (float*)d[1];
-    float* wb = (float*)d[2];
+    const float* __restrict__ w = (const float*)d[0];
+    float* __restrict__ wf = (float*)d[1];
+    float* __restrict__ wb = (float*)d[2];
     const int Cout = (int)d[3], Cin = (int)d[4], KH = (int)d[5], KW = (int)d[6], ldf = (int)d[7], ldb = (int)d[8];
-    const int64_t total = (int64_t)Cout * Cin * KH * KW;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        int64_t t = i;
-        const int kw = (int)(t % KW); t /= KW;
-        const int kh = (int)(t % KH); t /= KH;
-        const int ci = (int)(t % Cin); t /= Cin;
-        const int co = (int)t;
-        const float v = w[i];
-        if (wf) wf[((int64_t)(kh * KW + kw) * Cin + ci) * ldf + co] = v;
-        if (wb) wb[((int64_t)(kh * KW + kw) * Cout + co) * ldb + ci] = v;
+    const int T = KH * KW;
+    constexpr int TMAX = 9, TS = 32;
+    __shared__ float tile[TMAX][TS][TS + 1];
+    if (T > TMAX) {                                           // the 7x7 stem (Cin = 3): element-wise, it is tiny
+        const int64_t total = (int64_t)Cout * Cin * T;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            const int tap = (int)(i % T);
+            const int64_t r = i / T;
+            const int ci = (int)(r % Cin), co = (int)(r / Cin);
+            const float v = w[i];
+            if (wf) wf[((int64_t)tap * Cin + ci) * ldf + co] = v;
+            if (wb) wb[((int64_t)tap * Cout + co) * ldb + ci] = v;
+        }
+        return;
+    }
+    // 32 (cout) x 32 (cin) x T tiles through LDS: the read is contiguous along (ci, tap) of one cout row, the two writes
+    // are contiguous along cout (w_fwd) and along cin (w_bwd) -- a direct scatter runs at ~1 TB/s, 175 us per step
+    const int nct = (Cout + TS - 1) / TS, nit = (Cin + TS - 1) / TS;
+    for (int t = blockIdx.x; t < nct * nit; t += gridDim.x) {
+        const int co0 = (t / nit) * TS, ci0 = (t % nit) * TS;
+        const int nci = min(TS, Cin - ci0), nco = min(TS, Cout - co0);
+        const int row = nci * T;                              // contiguous floats of one cout row inside the tile
+        for (int e = threadIdx.x; e < nco * row; e += 256) {
+            const int co_l = e / row, rem = e - co_l * row;
+            const int ci_l = rem / T, tap = rem - ci_l * T;
+            tile[tap][co_l][ci_l] = w[((int64_t)(co0 + co_l) * Cin + ci0) * T + rem];
+        }
+        __syncthreads();
+        if (wf)
+            for (int e = threadIdx.x; e < T * nci * nco; e += 256) {
+                const int co_l = e % nco, r = e / nco;
+                const int ci_l = r % nci, tap = r / nci;
+                wf[((int64_t)tap * Cin + ci0 + ci_l) * ldf + co0 + co_l] = tile[tap][co_l][ci_l];
+            }
+        if (wb)
+            for (int e = threadIdx.x; e < T * nco * nci; e += 256) {
+                const int ci_l = e % nci, r = e / nci;
+                const int co_l = r % nco, tap = r / nco;
+                wb[((int64_t)tap * Cout + co0 + co_l) * ldb + ci0 + ci_l] = tile[tap][co_l][ci_l];
+            }
+        __syncthreads();
     }
 }
 
