@@ -881,29 +881,42 @@ __global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__
 }
 
 // d/dw, d/dbias: per-workgroup partial sums of dz[p] * x[src(p,tap), ci] (145 values), fixed-order second stage
+#define HEAD_PIX 320            // pixels of one workgroup's range staged in LDS per pass
 __global__ __launch_bounds__(256) void k_head_bwd_weight(const float* __restrict__ dz, const float* __restrict__ x, float* __restrict__ partials,
                                                          int B, int H, int W) {
     const int64_t N = (int64_t)B * H * W;
-    // thread t accumulates column t of the 145-vector (144 weights + bias) over this workgroup's pixel range; all threads
-    // walk the same pixels, so dz[n] is a broadcast read and the x reads of a wave stay inside 9 neighbouring pixels.
+    // thread t accumulates column t of the 145-vector (144 weights + bias) over this workgroup's pixel range.  The
+    // reflected source offsets of a pixel depend on the tap only, not on the channel: they are computed once per
+    // (pixel, tap) into LDS together with dz, so the 145 column threads run 2 LDS reads + 1 global load + 1 FMA per pixel
+    // (the first version recomputed the reflection in every thread: 137 us, VALU-bound).
+    __shared__ int soff[HEAD_PIX][9];
+    __shared__ float sdz[HEAD_PIX];
     const int col = threadIdx.x;
-    const int tap = col / HC, ci = col - tap * HC, kh = tap / 3, kw = tap - kh * 3;
+    const int tap = min(col / HC, 8), ci = col - (col / HC) * HC;
+    const bool wcol = col < 9 * HC, bcol = col == 9 * HC;
     float s = 0.f;
     const int64_t per = (N + gridDim.x - 1) / gridDim.x;
     const int64_t n0 = (int64_t)blockIdx.x * per, n1 = (n0 + per < N) ? n0 + per : N;
-    if (col < 9 * HC + 1 && n0 < n1) {
-        int b = (int)(n0 / ((int64_t)H * W));
-        const int r0 = (int)(n0 - (int64_t)b * H * W);
-        int h = r0 / W, ww = r0 - h * W;                       // advanced incrementally: no divisions in the pixel loop
-        for (int64_t n = n0; n < n1; ++n) {
-            const float g = dz[n];
-            if (col == 9 * HC) s += g;
-            else {
-                const int ys = reflect1(h + kh - 1, H), xs = reflect1(ww + kw - 1, W);
-                s = fmaf(g, x[(((int64_t)b * H + ys) * W + xs) * HC + ci], s);
-            }
-            if (++ww == W) { ww = 0; if (++h == H) { h = 0; ++b; } }
+    for (int64_t base = n0; base < n1; base += HEAD_PIX) {
+        const int cnt = (int)((n1 - base < HEAD_PIX) ? n1 - base : HEAD_PIX);
+        for (int e = threadIdx.x; e < cnt * 9; e += 256) {
+            const int i = e / 9, tp = e - i * 9, kh = tp / 3, kw = tp - kh * 3;
+            const int64_t n = base + i;
+            const int b = (int)(n / ((int64_t)H * W));
+            const int r = (int)(n - (int64_t)b * H * W);
+            const int h = r / W, ww = r - h * W;
+            const int ys = reflect1(h + kh - 1, H), xs = reflect1(ww + kw - 1, W);
+            soff[i][tp] = ((b * H + ys) * W + xs) * HC;        // < 2^31 elements (checked by the host)
         }
+        for (int i = threadIdx.x; i < cnt; i += 256) sdz[i] = dz[base + i];
+        __syncthreads();
+        if (wcol) {
+#pragma unroll 4
+            for (int i = 0; i < cnt; ++i) s = fmaf(sdz[i], x[soff[i][tap] + ci], s);
+        } else if (bcol) {
+            for (int i = 0; i < cnt; ++i) s += sdz[i];
+        }
+        __syncthreads();
     }
     if (col < 9 * HC + 1) partials[(int64_t)blockIdx.x * (9 * HC + 1) + col] = s;
 }
@@ -1088,6 +1101,7 @@ int64_t e2e_head_workspace_floats(void) { return (int64_t)HEAD_PARTS * (9 * HC +
 int e2e_head_bwd(const float* dz, const float* x, const float* w, float* dx, float* dw, float* dbias, float* workspace, int B, int H,
                  int W, int Cin, void* stream) {
     E2E_REQUIRE(dz && x && w && workspace && B > 0 && H >= 2 && W >= 2 && Cin == HC, E2E_ERR_ARG, "e2e_head_bwd: bad argument");
+    E2E_REQUIRE((int64_t)B * H * W * HC < (1ll << 31), E2E_ERR_ARG, "e2e_head_bwd: activation too large for 32-bit element offsets");
     hipStream_t st = (hipStream_t)stream;
     if (dx) hipLaunchKernelGGL(k_head_bwd_data, dim3(egrid((int64_t)B * H * W)), dim3(256), 0, st, dz, w, dx, B, H, W);
     if (dw) {
