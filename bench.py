@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--workload", default="warp", choices=["warp", "full"],
                     help="warp: BASELINE configs[1] (default). full: whole refinement step incl. depth network, 3-D loss, Adam, map update")
     ap.add_argument("--device-geometry", action="store_true", help="derive the geometry in the kernel from device K/inv_K/T (default: host kernel arguments)")
+    ap.add_argument("--steps-per-graph", type=int, default=3,
+                    help="steps captured per hipGraph replay (default 3 = the refinement steps of one keyframe, README.md:146-158 of the reference)")
+    ap.add_argument("--grad-only", action="store_true", help="diagnostic: skip the second-stage loss reduction (NOT the benchmark configuration)")
     ap.add_argument("--split", action="store_true", help="two-kernel form (e2e_warp_photo_fwd + _bwd) instead of the single-launch lossgrad")
     a = ap.parse_args()
     if a.steps is None:
@@ -172,7 +175,7 @@ def main():
             plan.forward()
             plan.backward()
         else:
-            plan.step()
+            plan.step(want_loss=not a.grad_only)
 
     side = torch.cuda.Stream(dev)
     graph = None
@@ -180,13 +183,27 @@ def main():
         for _ in range(3):
             step()
         side.synchronize()
+        G = 1 if a.no_graph else max(1, a.steps_per_graph)
+        graph_g = None
         if not a.no_graph:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
                 step()
-        run = graph.replay if graph is not None else step
-        for _ in range(a.warmup):
-            run()
+            if G > 1:                                   # one replay = the G refinement steps of one keyframe
+                graph_g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_g, stream=side):
+                    for _ in range(G):
+                        step()
+        run1 = graph.replay if graph is not None else step
+
+        def run_steps(n):                               # EXACTLY n steps: n // G replays of the G-step graph + the rest one by one
+            if graph_g is not None:
+                for _ in range(n // G):
+                    graph_g.replay()
+                n = n % G
+            for _ in range(n):
+                run1()
+        run_steps(a.warmup)
 
         def barrier():
             torch.cuda.synchronize(dev)
@@ -196,8 +213,7 @@ def main():
 
         barrier()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            run()
+        run_steps(a.steps)
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
         barrier()
@@ -241,7 +257,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic 640x480 RGB-D pair, warp+photometric(+l2 depth-reg) fwd+bwd kernels only",
-                       "pairs_per_launch": B, "height": H, "width": W, "launch": "eager" if graph is None else "hipGraph replay",
+                       "pairs_per_launch": B, "height": H, "width": W, "launch": "eager" if graph is None else f"hipGraph replay, {G} step(s) per replay",
                        "kernels_per_step": 3 if a.split else 2,
                        "geometry": "device matrices" if (a.split or B != 1 or a.device_geometry) else "host kernel arguments"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
