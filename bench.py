@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--device-geometry", action="store_true", help="derive the geometry in the kernel from device K/inv_K/T (default: host kernel arguments)")
     ap.add_argument("--steps-per-graph", type=int, default=3,
                     help="steps captured per hipGraph replay (default 3 = the refinement steps of one keyframe, README.md:146-158 of the reference)")
+    ap.add_argument("--two-kernel", action="store_true", help="lossgrad + second-stage reduce per step instead of the chained single-kernel form")
     ap.add_argument("--grad-only", action="store_true", help="diagnostic: skip the second-stage loss reduction (NOT the benchmark configuration)")
     ap.add_argument("--split", action="store_true", help="two-kernel form (e2e_warp_photo_fwd + _bwd) instead of the single-launch lossgrad")
     a = ap.parse_args()
@@ -191,9 +192,19 @@ def main():
                 step()
             if G > 1:                                   # one replay = the G refinement steps of one keyframe
                 graph_g = torch.cuda.CUDAGraph()
+                chained = not (a.split or a.grad_only or a.two_kernel)
+                if chained:
+                    step_losses = [torch.zeros_like(plan.loss) for _ in range(G)]
                 with torch.cuda.graph(graph_g, stream=side):
-                    for _ in range(G):
-                        step()
+                    if chained:
+                        # one kernel per step: launch k adds its fixed-point loss sums to slot set k and finalises step k-1's
+                        # loss; the last step of the replay is finished by the flush -- all G losses are final at replay end
+                        for k in range(G):
+                            plan.step_chain(k % 8, (k - 1) % 8 if k else -1, step_losses[k - 1] if k else None)
+                        plan.flush_chain((G - 1) % 8, step_losses[G - 1])
+                    else:
+                        for _ in range(G):
+                            step()
         run1 = graph.replay if graph is not None else step
 
         def run_steps(n):                               # EXACTLY n steps: n // G replays of the G-step graph + the rest one by one
@@ -257,8 +268,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic 640x480 RGB-D pair, warp+photometric(+l2 depth-reg) fwd+bwd kernels only",
-                       "pairs_per_launch": B, "height": H, "width": W, "launch": "eager" if graph is None else f"hipGraph replay, {G} step(s) per replay",
-                       "kernels_per_step": 3 if a.split else 2,
+                       "pairs_per_launch": B, "height": H, "width": W, "launch": "eager" if graph is None else f"hipGraph replay, {G} step(s) per replay" + (", chained launches (1 kernel per step + 1 flush per replay)" if (G > 1 and not (a.split or a.grad_only or a.two_kernel)) else ""),
+                       "kernels_per_step": 3 if a.split else (2 if (G == 1 or a.two_kernel or a.grad_only) else round(1 + 1 / G, 3)),
                        "geometry": "device matrices" if (a.split or B != 1 or a.device_geometry) else "host kernel arguments"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_NOTE.get((a.split, B), None),

@@ -34,6 +34,43 @@ struct HostGeo {       // c = d * (M [x,y,1]) + p4 : rows of M (9) then p4 (3); 
     int use;
 };
 
+// Chained launches (e2e_warp_photo_lossgrad_chain): instead of leaving per-workgroup partial sums for a second-stage
+// kernel, every workgroup adds its partial sums -- converted to 2^-36 fixed point, so the integer sum is independent of
+// the arrival order and bitwise reproducible -- into one of 64 slots of slot set `cur`, and workgroup 0 turns the
+// COMPLETE set `prev` of the previous launch into that launch's loss and clears it.  One kernel per step; the last
+// step of a chain is finished by e2e_warp_photo_lossgrad_chain_flush.  (64 slots: same-address device atomics
+// serialise at ~0.18 us each, 600 workgroups on one address would cost 100 us.)
+#define CHAIN_SLOTS 64
+#define CHAIN_SET_U64 (2 * CHAIN_SLOTS + 1)          // two sums x 64 slots + a "non-finite partial" flag
+#define CHAIN_SETS 8
+#define CHAIN_FIX 68719476736.0f                     // 2^36
+struct Chain {
+    unsigned long long* slots;                        // NULL: classic mode (partials + second-stage kernel)
+    int cur, prev;                                    // prev < 0: nothing to finalise
+    float* loss_prev;
+    double scale;                                     // 1 / (B H W)
+    int prev_sets;                                    // 2 when the regulariser sum exists, else 1
+};
+
+__device__ __forceinline__ void chain_finalise(unsigned long long* set, int nsums, double scale, float* out, int lane) {
+    // one wave: lane l owns slot l of both sums
+    unsigned long long v0 = set[lane], v1 = (nsums > 1) ? set[CHAIN_SLOTS + lane] : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        v0 += __shfl_xor(v0, o, 64);
+        v1 += __shfl_xor(v1, o, 64);
+    }
+    const bool bad = set[2 * CHAIN_SLOTS] != 0ull;
+    set[lane] = 0ull;
+    set[CHAIN_SLOTS + lane] = 0ull;
+    if (lane == 0) {
+        set[2 * CHAIN_SLOTS] = 0ull;
+        const float nanv = __uint_as_float(0x7FC00000u);
+        out[0] = bad ? nanv : (float)((double)v0 * (1.0 / (double)CHAIN_FIX) * scale);
+        out[1] = (nsums > 1) ? (bad ? nanv : (float)((double)v1 * (1.0 / (double)CHAIN_FIX) * scale)) : 0.f;
+    }
+}
+
 struct Taps {          // what the adjoint needs about one of the thread's own pixels
     float nw[3], ne[3], sw[3], se[3];
     float tx, ty, mx, my;   // bilinear fractions, d(ix)/d(u) and d(iy)/d(v) (0 where the border clamp is active)
@@ -49,7 +86,7 @@ __global__ __launch_bounds__(LNT) void k_warp_photo_lossgrad(
     const float* __restrict__ invK, const float* __restrict__ T, int use_mask, int reg_kind,
     const float* __restrict__ ri_t, const float* __restrict__ ri_s, const float* __restrict__ d_s,
     float w_photo, float w_reg, float* __restrict__ g_dt, float* __restrict__ g_ds,
-    float* __restrict__ partials, int B, int H, int W, HostGeo hg) {
+    float* __restrict__ partials, int B, int H, int W, HostGeo hg, Chain chain) {
     constexpr int LT_H = 8 * PPT, LX_H = LT_H + 4, LG_H = LT_H + 2;
     constexpr int N_HALO = LX_W * LX_H - LT_W * LT_H;      // 176 (PPT 1) / 208 (PPT 2)
     constexpr int NE = PPT + 1;                            // warp evaluations per thread
@@ -382,12 +419,37 @@ __global__ __launch_bounds__(LNT) void k_warp_photo_lossgrad(
     const int nblk = gridDim.x * gridDim.y * gridDim.z;
     const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const float s0 = block_sum(lsum, red);
-    if (tid == 0) partials[blk] = s0;
+    float s1 = 0.f;
     if (reg_kind) {
         __syncthreads();
-        const float s1 = block_sum(rsum, red);
-        if (tid == 0) partials[nblk + blk] = s1;
+        s1 = block_sum(rsum, red);
     }
+    if (chain.slots == nullptr) {
+        if (tid == 0) {
+            partials[blk] = s0;
+            if (reg_kind) partials[nblk + blk] = s1;
+        }
+        return;
+    }
+    if (tid == 0) {
+        unsigned long long* set = chain.slots + (size_t)chain.cur * CHAIN_SET_U64;
+        const int slot = blk & (CHAIN_SLOTS - 1);
+        // finite, non-negative and small enough that the 2^-36 fixed-point total of all workgroups stays below 2^64
+        const float lim = 2.6e8f / (float)nblk;
+        const bool ok = s0 >= 0.f && s0 < lim && (!reg_kind || (s1 >= 0.f && s1 < lim));
+        if (ok) {
+            atomicAdd(&set[slot], (unsigned long long)(s0 * CHAIN_FIX));
+            if (reg_kind) atomicAdd(&set[CHAIN_SLOTS + slot], (unsigned long long)(s1 * CHAIN_FIX));
+        } else {
+            atomicOr(&set[2 * CHAIN_SLOTS], 1ull);
+        }
+    }
+    if (blk == 0 && chain.prev >= 0 && tid < 64)
+        chain_finalise(chain.slots + (size_t)chain.prev * CHAIN_SET_U64, chain.prev_sets, chain.scale, chain.loss_prev, tid);
+}
+
+__global__ __launch_bounds__(64) void k_chain_flush(unsigned long long* set, int nsums, double scale, float* out) {
+    chain_finalise(set, nsums, scale, out, threadIdx.x);
 }
 
 // second stage: fixed-order sum of the per-workgroup partials (1 workgroup, loads issued up front)
@@ -425,15 +487,21 @@ extern "C" {
 
 int64_t e2e_warp_photo_lossgrad_workspace_floats(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    // 2 partial sums per workgroup of the finest tiling (32x8)
-    return 2ll * e2e_ceil_div(W, LT_W) * e2e_ceil_div(H, 8) * B;
+    // 2 partial sums per workgroup of the finest tiling (32x8), then (8-byte aligned) the slot sets of the chained mode
+    const int64_t parts = (2ll * e2e_ceil_div(W, LT_W) * e2e_ceil_div(H, 8) * B + 1) / 2 * 2;
+    return parts + 2ll * CHAIN_SETS * CHAIN_SET_U64;
+}
+
+static unsigned long long* chain_area(float* workspace, int B, int H, int W) {
+    const int64_t parts = (2ll * e2e_ceil_div(W, LT_W) * e2e_ceil_div(H, 8) * B + 1) / 2 * 2;
+    return (unsigned long long*)(workspace + parts);
 }
 
 static int lossgrad_impl(const float* depth_tgt, const float* src, e2e_strides ss, const float* tgt, e2e_strides ts,
                          const float* K, const float* inv_K, const float* T, HostGeo hg, int use_mask, int padding_mode,
                          int reg_kind, const float* reg_init_tgt, const float* reg_init_src, const float* depth_src,
                          float w_photo, float w_reg, float* loss_out, float* g_depth_tgt, float* g_depth_src,
-                         float* workspace, int B, int H, int W, void* stream) {
+                         float* workspace, int B, int H, int W, void* stream, Chain chain = Chain{}) {
     E2E_REQUIRE(B > 0 && H > 1 && W > 1 && (int64_t)B * H * W * 3 < (1ll << 31), E2E_ERR_ARG,
                 "e2e_warp_photo_lossgrad: bad dims B=%d H=%d W=%d", B, H, W);
     E2E_REQUIRE(depth_tgt && src && tgt && (hg.use || (K && inv_K && T)) && g_depth_tgt && workspace, E2E_ERR_ARG,
@@ -452,7 +520,7 @@ static int lossgrad_impl(const float* depth_tgt, const float* src, e2e_strides s
     const bool nhwc = ss.sc == 1 && ss.sw == 3 && ss.sh == 3ll * W && ts.sc == 1 && ts.sw == 3 && ts.sh == 3ll * W;
     hipStream_t st = (hipStream_t)stream;
 #define LG_ARGS depth_tgt, src, ss, tgt, ts, K, inv_K, T, use_mask, reg_kind, reg_init_tgt, reg_init_src, depth_src, w_photo, w_reg, \
-                g_depth_tgt, g_depth_src, workspace, B, H, W, hg
+                g_depth_tgt, g_depth_src, workspace, B, H, W, hg, chain
 #define LG_LAUNCH(PADV, NH)                                                                                              \
     do {                                                                                                                 \
         if (ppt == 2) hipLaunchKernelGGL((k_warp_photo_lossgrad<PADV, NH, 2>), g, dim3(LT_W, 8), 0, st, LG_ARGS);        \
@@ -467,7 +535,7 @@ static int lossgrad_impl(const float* depth_tgt, const float* src, e2e_strides s
 #undef LG_LAUNCH
 #undef LG_ARGS
     E2E_LAUNCH_CHECK("e2e_warp_photo_lossgrad");
-    if (loss_out) {     // loss_out == NULL: gradients only (the per-workgroup partial sums stay in the workspace)
+    if (loss_out && !chain.slots) {     // loss_out == NULL: gradients only (the per-workgroup partial sums stay in the workspace)
         hipLaunchKernelGGL(k_reduce_partials2, dim3(1), dim3(RED_T), 0, st, workspace, nblk, reg_kind ? 2 : 1,
                            1.0 / ((double)B * H * W), loss_out);
         E2E_LAUNCH_CHECK("e2e_warp_photo_lossgrad(reduce)");
@@ -497,6 +565,36 @@ int e2e_warp_photo_lossgrad_hostgeo(const float* depth_tgt, const float* src, e2
     hg.use = 1;
     return lossgrad_impl(depth_tgt, src, ss, tgt, ts, nullptr, nullptr, nullptr, hg, use_mask, padding_mode, reg_kind, reg_init_tgt,
                          reg_init_src, depth_src, w_photo, w_reg, loss_out, g_depth_tgt, g_depth_src, workspace, 1, H, W, stream);
+}
+
+int e2e_warp_photo_lossgrad_chain(const float* depth_tgt, const float* src, e2e_strides ss, const float* tgt, e2e_strides ts,
+                                  const float* K, const float* inv_K, const float* T, const float* geometry12_host, int use_mask,
+                                  int padding_mode, int reg_kind, const float* reg_init_tgt, const float* reg_init_src,
+                                  const float* depth_src, float w_photo, float w_reg, int set_cur, int set_prev, float* loss_prev_out,
+                                  float* g_depth_tgt, float* g_depth_src, float* workspace, int B, int H, int W, void* stream) {
+    E2E_REQUIRE(set_cur >= 0 && set_cur < CHAIN_SETS && set_prev < CHAIN_SETS && set_prev != set_cur && (set_prev < 0 || loss_prev_out),
+                E2E_ERR_ARG, "e2e_warp_photo_lossgrad_chain: slot sets must be distinct and in [0, %d); set_prev >= 0 needs loss_prev_out", CHAIN_SETS);
+    E2E_REQUIRE(!geometry12_host || B == 1, E2E_ERR_ARG, "e2e_warp_photo_lossgrad_chain: host geometry describes one pair (B == 1)");
+    E2E_REQUIRE(workspace && B > 0 && H > 1 && W > 1, E2E_ERR_ARG, "e2e_warp_photo_lossgrad_chain: bad argument");
+    HostGeo hg{};
+    hg.use = geometry12_host ? 1 : 0;
+    if (geometry12_host)
+        for (int i = 0; i < 12; ++i) hg.g[i] = geometry12_host[i];
+    Chain c{};
+    c.slots = chain_area(workspace, B, H, W);
+    c.cur = set_cur; c.prev = set_prev; c.loss_prev = loss_prev_out;
+    c.scale = 1.0 / ((double)B * H * W);
+    c.prev_sets = reg_kind ? 2 : 1;
+    return lossgrad_impl(depth_tgt, src, ss, tgt, ts, K, inv_K, T, hg, use_mask, padding_mode, reg_kind, reg_init_tgt, reg_init_src,
+                         depth_src, w_photo, w_reg, nullptr, g_depth_tgt, g_depth_src, workspace, B, H, W, stream, c);
+}
+
+int e2e_warp_photo_lossgrad_chain_flush(float* workspace, int set, int reg_kind, float* loss_out, int B, int H, int W, void* stream) {
+    E2E_REQUIRE(workspace && loss_out && set >= 0 && set < CHAIN_SETS && B > 0 && H > 1 && W > 1, E2E_ERR_ARG, "e2e_warp_photo_lossgrad_chain_flush: bad argument");
+    hipLaunchKernelGGL(k_chain_flush, dim3(1), dim3(64), 0, (hipStream_t)stream, chain_area(workspace, B, H, W) + (size_t)set * CHAIN_SET_U64,
+                       reg_kind ? 2 : 1, 1.0 / ((double)B * H * W), loss_out);
+    E2E_LAUNCH_CHECK("e2e_warp_photo_lossgrad_chain_flush");
+    return E2E_OK;
 }
 
 }  // extern "C"

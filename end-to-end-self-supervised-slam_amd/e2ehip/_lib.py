@@ -45,6 +45,9 @@ SIGNATURES = {
     "e2e_warp_photo_lossgrad_workspace_floats": [c_int, c_int, c_int],
     "e2e_warp_photo_lossgrad": [c_fp, c_fp, Strides, c_fp, Strides, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp,
                                 c_f32, c_f32, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "e2e_warp_photo_lossgrad_chain": [c_fp, c_fp, Strides, c_fp, Strides, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp,
+                                      c_f32, c_f32, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "e2e_warp_photo_lossgrad_chain_flush": [c_fp, c_int, c_int, c_fp, c_int, c_int, c_int, c_fp],
     "e2e_warp_photo_lossgrad_hostgeo": [c_fp, c_fp, Strides, c_fp, Strides, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_f32, c_f32,
                                         c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp],
     "e2e_vertex_normal_maps": [c_fp, c_fp, c_fp, c_f32, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],

@@ -86,6 +86,24 @@ class LossGradPlan(WarpPhotoPlan):
         self._geo = (ctypes.c_float * 12)(*[float(v) for v in M.reshape(-1)], *[float(v) for v in P[:, 3]])
         return self
 
+    def step_chain(self, set_cur, set_prev=-1, loss_prev=None):
+        """One kernel for the whole step: the loss sums go to slot set `set_cur` (0..7) and the previous chained launch's
+        set `set_prev` is finalised into `loss_prev` (a 2-float tensor).  Finish the last step with flush_chain().
+        -> (g_depth_tgt, g_depth_src)."""
+        dt, ds, it, is_, src, tgt, K, iK, T = self.t
+        geo = getattr(self, "_geo", None)
+        L.call("e2e_warp_photo_lossgrad_chain", L.ptr(dt), L.ptr(src), L.strides4(src), L.ptr(tgt), L.strides4(tgt),
+               None if geo is not None else L.ptr(K), None if geo is not None else L.ptr(iK), None if geo is not None else L.ptr(T),
+               ctypes.cast(geo, ctypes.c_void_p) if geo is not None else None, self.use_mask, self.pad, self.reg,
+               L.ptr(it) if self.reg else None, L.ptr(is_) if self.reg else None, L.ptr(ds) if self.reg else None, self.w_photo, self.w_reg,
+               int(set_cur), int(set_prev), L.ptr(loss_prev) if set_prev >= 0 else None, L.ptr(self.g_depth_tgt),
+               L.ptr(self.g_depth_src) if self.reg else None, L.ptr(self.ws), self.B, self.H, self.W, L.stream())
+        return self.g_depth_tgt, self.g_depth_src
+
+    def flush_chain(self, set_last, loss_out):
+        L.call("e2e_warp_photo_lossgrad_chain_flush", L.ptr(self.ws), int(set_last), self.reg, L.ptr(loss_out), self.B, self.H, self.W, L.stream())
+        return loss_out
+
     def step(self, want_loss=True):
         """-> (loss[2], g_depth_tgt, g_depth_src); gradients are of w_photo*loss[0] + w_reg*loss[1].
         want_loss=False launches the main kernel only (no second-stage reduction of the loss)."""

@@ -163,6 +163,26 @@ int e2e_warp_photo_lossgrad_hostgeo(const float* depth_tgt, const float* src, e2
                                     float* g_depth_tgt, float* g_depth_src, float* workspace, int H,
                                     int W, void* stream);
 
+/* Chained form: ONE kernel per step.  Each workgroup adds its partial loss sums (as 2^-36 fixed
+ * point: the integer total does not depend on arrival order, so the result is bitwise reproducible)
+ * into slot set `set_cur` of the workspace, and the launch also turns the complete slot set
+ * `set_prev` of the PREVIOUS launch into that launch's loss (loss_prev_out[0..1]) and clears it
+ * (set_prev < 0: nothing to finalise).  Sets are 0..7 and must alternate; the last launch of a chain
+ * is finished by e2e_warp_photo_lossgrad_chain_flush.  geometry12_host non-NULL (B == 1) replaces
+ * K / inv_K / T as in e2e_warp_photo_lossgrad_hostgeo.  The workspace (same size function) must be
+ * zero-filled once before the first chained launch.  A per-workgroup sum that is negative, not
+ * finite or above 2.6e8 / #workgroups turns the loss into NaN (the gradients are unaffected). */
+int e2e_warp_photo_lossgrad_chain(const float* depth_tgt, const float* src, e2e_strides src_strides,
+                                  const float* tgt, e2e_strides tgt_strides, const float* K,
+                                  const float* inv_K, const float* T, const float* geometry12_host,
+                                  int use_mask, int padding_mode, int reg_kind, const float* reg_init_tgt,
+                                  const float* reg_init_src, const float* depth_src, float w_photo,
+                                  float w_reg, int set_cur, int set_prev, float* loss_prev_out,
+                                  float* g_depth_tgt, float* g_depth_src, float* workspace, int B, int H,
+                                  int W, void* stream);
+int e2e_warp_photo_lossgrad_chain_flush(float* workspace, int set, int reg_kind, float* loss_out, int B,
+                                        int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* RGB-D unprojection and the PointFusion map step -- gradslam (un-vendored dependency; semantics */
 /* per SURVEY.md Appendix A), reference call sites online_adaption.py:347-363, :461-469, :642      */

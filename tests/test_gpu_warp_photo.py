@@ -259,3 +259,45 @@ def test_lossgrad_host_geometry_matches_device_geometry():
     _close(lb[0], lp, what="photometric")
     _gdepth_close(gb, dc.grad, grid, what="g depth_tgt (host geometry)")
     assert torch.equal(gsb, gsa)
+
+
+@pytest.mark.parametrize("B,reg,hostgeo", [(1, "l2", True), (2, "l1", False), (1, None, False)])
+def test_lossgrad_chain_equals_two_kernel_form(B, reg, hostgeo):
+    """Chained launches (one kernel per step, fixed-point slot sums finalised by the next launch / the flush) give the
+    same gradients bit for bit and the same losses to 1e-6, for several steps with changing depth, and are reproducible."""
+    from e2ehip.fused import LossGradPlan
+    H, W = 75, 101
+    s = make_pair(H, W, seed=9, B=B)
+    gen = torch.Generator().manual_seed(9)
+    dsrc = s["depth"] + 0.1 * torch.rand(s["depth"].shape, generator=gen)
+    depth = s["depth"].to(DEV).clone()
+    args = (depth, dsrc.to(DEV), (s["depth"] + 0.05).to(DEV), (dsrc + 0.05).to(DEV), s["src"].to(DEV).permute(0, 3, 1, 2),
+            s["tgt"].to(DEV).permute(0, 3, 1, 2), s["K"].to(DEV), s["invK"].to(DEV), s["T"].to(DEV))
+    mk = lambda: LossGradPlan(B, H, W, torch.device(DEV), "border", True, reg, 1.0, 1e-2).bind(*args)
+    ref, ch = mk(), mk()
+    if hostgeo:
+        for p in (ref, ch):
+            p.set_host_geometry(s["K"][0], s["invK"][0], s["T"][0])
+    steps = 5
+    ref_losses, ref_grads = [], []
+    for k in range(steps):
+        depth.copy_(s["depth"].to(DEV) * (1.0 + 0.01 * k))
+        l, g, _ = ref.step()
+        ref_losses.append(l.clone()); ref_grads.append(g.clone())
+    for rep in range(2):                                            # twice: the slot sets must come back clean
+        losses = [torch.full((2,), -1.0, device=DEV) for _ in range(steps)]
+        for k in range(steps):
+            depth.copy_(s["depth"].to(DEV) * (1.0 + 0.01 * k))
+            g, _ = ch.step_chain(k % 3, (k - 1) % 3 if k else -1, losses[k - 1] if k else None)
+            assert torch.equal(g, ref_grads[k])
+        ch.flush_chain((steps - 1) % 3, losses[steps - 1])
+        for k in range(steps):
+            torch.testing.assert_close(losses[k][0], ref_losses[k][0], rtol=1e-6, atol=1e-9)
+            if reg:
+                torch.testing.assert_close(losses[k][1], ref_losses[k][1], rtol=1e-6, atol=1e-9)
+        if rep == 0:
+            first = [l.clone() for l in losses]
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(first, losses))   # bitwise reproducible (integer sums)
+    with pytest.raises(Exception):
+        ch.step_chain(1, 1, losses[0])                                  # sets must differ
