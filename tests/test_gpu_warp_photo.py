@@ -301,3 +301,32 @@ def test_lossgrad_chain_equals_two_kernel_form(B, reg, hostgeo):
             assert all(torch.equal(a, b) for a, b in zip(first, losses))   # bitwise reproducible (integer sums)
     with pytest.raises(Exception):
         ch.step_chain(1, 1, losses[0])                                  # sets must differ
+
+
+def test_lossgrad_chain_keeps_non_finite_losses_visible_and_tiny_images():
+    """A NaN in the inputs must surface as a NaN loss in the chained form too (fixed-point sums cannot carry it: a flag
+    slot does); and the chain works on images smaller than one tile."""
+    from e2ehip.fused import LossGradPlan
+    for (H, W, poison) in ((3, 5, False), (40, 33, True)):
+        s = make_pair(H, W, seed=4)
+        tgt = s["tgt"].clone()
+        if poison:
+            tgt[0, 7, 9, 1] = float("nan")
+        args = (s["depth"].to(DEV), None, None, None, s["src"].to(DEV).permute(0, 3, 1, 2), tgt.to(DEV).permute(0, 3, 1, 2),
+                s["K"].to(DEV), s["invK"].to(DEV), s["T"].to(DEV))
+        ref = LossGradPlan(1, H, W, torch.device(DEV), "border", True, None).bind(*args)
+        l_ref, g_ref, _ = ref.step()
+        ch = LossGradPlan(1, H, W, torch.device(DEV), "border", True, None).bind(*args)
+        out = torch.zeros(2, device=DEV)
+        g, _ = ch.step_chain(0)
+        ch.flush_chain(0, out)
+        if poison:
+            assert torch.isnan(l_ref[0]) and torch.isnan(out[0])
+        else:
+            torch.testing.assert_close(out[0], l_ref[0], rtol=1e-6, atol=1e-9)
+            assert torch.equal(g, g_ref)
+        out2 = torch.zeros(2, device=DEV)                       # the flag and the slots were cleared by the flush
+        ch.bind(*((s["depth"].to(DEV),) + args[1:5] + (s["tgt"].to(DEV).permute(0, 3, 1, 2),) + args[6:]))
+        ch.step_chain(1)
+        ch.flush_chain(1, out2)
+        assert torch.isfinite(out2[0])
