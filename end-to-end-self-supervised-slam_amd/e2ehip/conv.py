@@ -1,6 +1,7 @@
 """Native convolutions of the depth network (csrc/conv.hip): fp32-MFMA implicit GEMM with the gather
 (stride, zero / reflection padding, nearest x2 upsample + channel concat) and the epilogue (folded eval-BN /
 bias, residual add, ReLU / ELU / disparity head) fused.  Tensors are NCHW-shaped, channels_last in memory."""
+import ctypes
 import weakref
 
 import torch
@@ -23,13 +24,36 @@ WEIGHT_EPOCH = [0]
 DIRECT_WGRAD = [False]
 
 
+_SIDE = {}              # device -> stream that runs the backward-weight chains of direct_weight_grads(overlap=True)
+
+
 class direct_weight_grads:
+    """overlap=True additionally moves every backward-weight chain (GEMM + slab folds + reduce) to a second stream: it
+    depends only on dZ, like the backward-data GEMM next to it, and two half-empty MFMA kernels side by side fill the
+    SIMDs better than one after the other.  The context exit joins the streams."""
+
+    def __init__(self, overlap=False):
+        self.overlap = overlap
+
     def __enter__(self):
-        self.prev = DIRECT_WGRAD[0]
+        self.prev = (DIRECT_WGRAD[0], OVERLAP[0])
         DIRECT_WGRAD[0] = True
+        OVERLAP[0] = self.overlap
 
     def __exit__(self, *exc):
-        DIRECT_WGRAD[0] = self.prev
+        DIRECT_WGRAD[0], OVERLAP[0] = self.prev
+        for side in _SIDE.values():
+            torch.cuda.current_stream(side.device).wait_stream(side)
+
+
+OVERLAP = [False]
+
+
+def _side_stream(dev):
+    s = _SIDE.get(dev)
+    if s is None:
+        s = _SIDE[dev] = torch.cuda.Stream(dev)
+    return s
 
 
 def _sink(param, shape):
@@ -250,8 +274,16 @@ class _Conv2d(torch.autograd.Function):
             gb = (sb if direct else torch.empty(Cout, device=dev, dtype=torch.float32)) if want_b else None
             ws = torch.empty(L.load().e2e_conv2d_wgrad_workspace_floats(B, Ho, Wo, Cin, Cout, KH, KW, 1 if gb is not None else 0),
                              device=dev, dtype=torch.float32)
+            st_w = st
+            if direct and OVERLAP[0]:
+                side = _side_stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))          # dZ (and everything before it) is ready
+                for t in (dZ, src0, src1, ws):
+                    if t is not None:
+                        t.record_stream(side)
+                st_w = ctypes.c_void_p(side.cuda_stream)
             L.call("e2e_conv2d_bwd_weight", L.ptr(dZ), L.ptr(src0), L.ptr(src1), C1, up, L.ptr(gw), L.ptr(gb), L.ptr(ws), B, Hs, Ws, Cin,
-                   Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, 1 if direct else 0, isub, imul, st)
+                   Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, 1 if direct else 0, isub, imul, st_w)
             if direct:
                 gw = gb = None
         return g0, g1, gw, gb, None, None, d_res, None, None, None, None, None, None, None, None

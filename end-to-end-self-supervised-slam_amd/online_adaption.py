@@ -178,7 +178,7 @@ class SLAM:
                 l3 = self.compute_3d_loss(d_tgt, K, poses[:, 1], T)
                 roots.append(l3 * a.LOSS.three3d_loss_weight)
                 grads.append(None)
-            with e2e_conv.direct_weight_grads():      # weight gradients accumulate straight into FusedAdam's flat bucket
+            with e2e_conv.direct_weight_grads(overlap=os.environ.get("E2E_WGRAD_OVERLAP", "1") == "1"):      # weight gradients accumulate straight into FusedAdam's flat bucket
                 torch.autograd.backward(roots, grads)
             self._exchange_gradients()
             self.optimizer.step()
