@@ -12,10 +12,12 @@
 // and a second kernel computes backward-weight as a split-K GEMM over pixels with fixed-order slab reduction.
 //
 // Tiling: workgroup = WM x WN waves, each wave owns 32 rows x (32*TN) columns (TN accumulators of 16 VGPRs);
-// K is consumed in chunks of 16 through double-buffered LDS tiles stored k-major so that both MFMA operands are
-// bank-conflict-free ds_read_b32 (lane l reads [k = 2kk + (l>>5)][i = l & 31]).  fp32 MFMA issues one instruction per
-// 64 cycles per SIMD, so one wave per SIMD with its accumulators in flight saturates the matrix pipe; global loads of
-// the next chunk are issued before the current chunk's MFMAs.
+// K is consumed in chunks of 32 (16 where Cin % 32 != 0) through double-buffered LDS tiles stored k-major so that both
+// MFMA operands are bank-conflict-free ds_read_b32 (lane l reads [k = 2kk + (l>>5)][i = l & 31]).  fp32 MFMA issues one
+// instruction per 64 cycles per SIMD, so one wave per SIMD with its accumulators in flight saturates the matrix pipe;
+// global loads of the next chunk are issued before the current chunk's MFMAs.  Operands are gathered through buffer
+// resources with 32-bit offsets: padding, stride holes and tile tails are out-of-range offsets that the hardware
+// answers with zeros, so the K loop has no branches and no 64-bit address arithmetic.
 #include "e2e_common.h"
 
 typedef float f4v __attribute__((ext_vector_type(4)));

@@ -11,10 +11,15 @@
 //   phase 1  warp every position of the tile + 2-px halo (36x20): {x,y} = {synth*m, tgt*m} -> LDS as
 //            float2 (one ds_read_b64 serves both SSIM operands; window sums run on v_pk_*_f32);
 //            the thread keeps its own two pixels' taps / projection in registers for the adjoint.
-//   phase 2  SSIM statistics at every q of tile + 1-px halo (34x18): loss contribution of the tile's
-//            own pixels and (G1,G2,G3) = upstream * dS/d(mu_x, E[x^2], E[xy]) -> LDS as float4.
+//   phase 2  SSIM statistics at every q of tile + 1-px halo (34x18), walked as 3 x 5 x 34 (channel, 4-row
+//            strip, column) units, two per thread, two vertically adjacent q's per v_pk_* operation:
+//            loss contribution of the tile's own pixels and (G1,G2,G3) = upstream *
+//            dS/d(mu_x, E[x^2], E[xy]) -> nine LDS planes.
 //   phase 3  per pixel: fold the 3x3 neighbourhood of G back (reflect-pad adjoint = multiplicities
 //            at the image border), bilinear-tap adjoint from the kept registers, chain to depth.
+// The loss sums leave the kernel either as per-workgroup partials for k_reduce_partials2 (classic)
+// or, in the chained form, as order-independent fixed-point slot sums that the NEXT launch finalises
+// (one kernel per step).
 // fp contraction is ON here (FMA): tolerance for this path is 1e-4 relative (BASELINE.json); the
 // bit-exact index kernels live in other files with contraction off.
 #include <stdlib.h>
