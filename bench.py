@@ -254,12 +254,25 @@ def main():
             launch_ms = {"warp_photo_fwd+reduce": fwd_ms, "warp_photo_bwd": bwd_ms}
             alg = {"fwd": fwd_bytes, "bwd": bwd_bytes}
         else:
-            # the dominant kernel ALONE (k_warp_photo_lossgrad, no second-stage reduce), one HIP event pair per launch
-            dom_ms = kernel_ms(lambda: plan.step(want_loss=False))
+            # the dominant kernel ALONE (k_warp_photo_lossgrad, no second-stage reduce).  One HIP event pair per launch
+            # over-reports a 11 us kernel by ~2 us (event + eager launch overhead), so the figure used for the roofline
+            # is a captured run of 20 back-to-back launches between ONE event pair, divided by 20 -- this is what
+            # rocprofv3's average duration agrees with (profiles/r01_final_summaries.md); the per-launch number stays in
+            # launch_ms for reference.
+            dom_eager_ms = kernel_ms(lambda: plan.step(want_loss=False))
             both_ms = kernel_ms(plan.step)
+            dom_ms = dom_eager_ms
+            if not a.no_graph:
+                RUN = 20
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk, stream=side):
+                    for _ in range(RUN):
+                        plan.step(want_loss=False)
+                dom_ms = kernel_ms(gk.replay, reps=60) / RUN
             # single launch: reads depth 4N + src 12N + tgt 12N + reg (init_t, init_s, depth_s) 12N; writes g_tgt 4N + g_src 4N
             dom, dom_bytes = "k_warp_photo_lossgrad", 48 * N
-            launch_ms = {"k_warp_photo_lossgrad": dom_ms, "lossgrad+reduce (both launches of a step)": both_ms}
+            launch_ms = {"k_warp_photo_lossgrad": dom_ms, "k_warp_photo_lossgrad (one event pair per eager launch)": dom_eager_ms,
+                         "lossgrad+reduce (both launches of a step, eager)": both_ms}
             alg = {"lossgrad": dom_bytes, "survey_8d_fused_minimum_equiv": (92 + 24) * N}
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     if rank == 0:
