@@ -78,6 +78,24 @@ def cpu_baseline(H, W, budget_s=12.0):
             "sample": f"{n} fwd+bwd steps of the same 1x{H}x{W} warp+photometric+reg workload ({el:.1f} s), torch CPU, {cores} threads (best of a short sweep)"}
 
 
+def cpu_baseline_full(H, W, threads=16):
+    """The oracle's refinement step (depth net forward + backward on the pair, median scaling, warp + photometric +
+    regulariser, Adam) on this node's host cores -- WITHOUT the 3-D nearest-neighbour loss and without the map step: the
+    reference's CPU KNN alone takes 10^2-10^3 s per step at this size, far outside a bounded sample."""
+    from e2ehip.synthetic import make_sequence
+    from oracle import depthnet, refine
+    ncpu = os.cpu_count() or 1
+    cores = min(threads, ncpu)
+    torch.set_num_threads(cores)
+    colors, depths, intr, poses = make_sequence(2, H, W, seed=1234)[:4]          # CPU tensors, colours in [0, 1]
+    r = refine.Refiner(depthnet.random_state_dict(0))
+    t0 = time.perf_counter()
+    recs = r.refine_pair(colors, depths, poses, intr, update_map=False)
+    el = time.perf_counter() - t0
+    return {"value": len(recs) / el, "unit": "steps/s", "cores": cores, "kind": "port", "host_cpus": ncpu,
+            "sample": f"{len(recs)} refinement steps of one 1x{H}x{W} keyframe pair ({el:.1f} s), torch CPU, {cores} threads; 3-D KNN loss and map step excluded"}
+
+
 def full_step_bench(a, rank, world, dev):
     """Whole refinement steps (BASELINE configs[2] shape on a synthetic sequence): per keyframe pair 3 x (network fwd+bwd on the
     pair, median scale, fused warp/photometric/regulariser, 3-D nearest-neighbour loss against the map, Adam) + the map update."""
@@ -108,7 +126,10 @@ def full_step_bench(a, rank, world, dev):
     nsteps = a.steps * cfg.OPTIMIZATION.refinement_steps
     if rank == 0:
         from e2ehip import nn_ops
-        print(json.dumps({"metric": "online refinement steps/sec @640x480", "value": world * nsteps / el, "unit": "steps/s", "n_gpus": world,
+        extra = {}
+        if world == 1 and not a.no_cpu_baseline:
+            extra["cpu_baseline"] = cpu_baseline_full(H, W)
+        print(json.dumps({**extra, "metric": "online refinement steps/sec @640x480", "value": world * nsteps / el, "unit": "steps/s", "n_gpus": world,
                           "steps": nsteps, "warmup": a.warmup * 3, "ms_per_step": 1e3 * el / nsteps, "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "full refinement step (depth net fwd+bwd on the pair, median scale, fused warp+photometric+reg, "

@@ -50,7 +50,7 @@ class Refiner:
         """colors (1,2,H,W,3) -> [depth0, depth1] each (1,1,H,W) = 1/disp (online_adaption.py:281-282)."""
         return [1 / depthnet.disp_forward(self.sd, colors[:, i]) for i in range(2)]
 
-    def refine_pair(self, colors, gt_depths, poses, K):
+    def refine_pair(self, colors, gt_depths, poses, K, update_map=True):
         """colors (1,2,H,W,3) in [0,1]; gt_depths (1,2,H,W,1); poses (1,2,4,4); K (1,1,4,4).
         Runs cfg.refinement_steps optimisation steps then the map step.  Returns per-step records."""
         cfg = self.cfg
@@ -89,8 +89,9 @@ class Refiner:
             rec["depth1"] = depths[1].detach()
             rec["metrics"] = [m.item() for m in warp_loss.depth_metrics(cfg.dataset, gt_depths[0][1], depths[1][0])]
             records.append(rec)
-        self.update_map(colors, gt_depths, poses, Kc)
-        self.first_iter = False
+        if update_map:                                     # False: bench.py's cpu_baseline times the refinement steps only
+            self.update_map(colors, gt_depths, poses, Kc)
+            self.first_iter = False
         return records
 
     @torch.no_grad()
