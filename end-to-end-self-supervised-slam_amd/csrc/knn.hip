@@ -101,7 +101,8 @@ struct GridInfo {
     float origin[3], h, inv_h;
     int dims[3];
     unsigned int n_unresolved;
-};
+    float eps;                 // absolute slack of every geometric bound: fp32 rounding of (v - origin) * inv_h at the cloud's
+};                             // largest coordinate can move a point across a cell face by a few ulps of that coordinate
 
 __device__ __forceinline__ unsigned int fkey(float f) {
     const unsigned int b = __float_as_uint(f);
@@ -177,6 +178,9 @@ __global__ __launch_bounds__(BBOX_BLOCKS) void k_grid_setup(GridInfo* gi, const 
         ext = fmaxf(ext, fkey_inv(gi->bb[3 + c]) - lo[c]);
     }
     const float h = fmaxf(ext / (float)(gmax - 1), GRID_HMIN);
+    float maxabs = 0.f;
+    for (int c = 0; c < 3; ++c) maxabs = fmaxf(maxabs, fmaxf(fabsf(lo[c]), fabsf(fkey_inv(gi->bb[3 + c]))));
+    gi->eps = 1e-5f + 2e-6f * maxabs;                              // ~16 ulps of the largest coordinate
     gi->h = h;
     gi->inv_h = 1.0f / h;
     for (int c = 0; c < 3; ++c) {
@@ -285,6 +289,7 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
     const float x = p1[i * 3], y = p1[i * 3 + 1], z = p1[i * 3 + 2];
     const float q[3] = {x, y, z};
     const float h = gi->h, ih = gi->inv_h;
+    const float eps = gi->eps + 2e-6f * fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));      // + the query's own rounding scale
     const int dims[3] = {gi->dims[0], gi->dims[1], gi->dims[2]};
     const float org[3] = {gi->origin[0], gi->origin[1], gi->origin[2]};
     int cq[3];
@@ -303,11 +308,11 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
             // the best distance so far (<=, a tie with a smaller index may hide there).  Bounds are shrunk by the same
             // safety margin as the stop test because points sit in their cells only up to fp32 rounding.
             const float gz = fmaxf(fmaxf(org[2] + (float)cz * h - z, z - (org[2] + (float)(cz + 1) * h)), 0.f);
-            const float gzs = fmaxf(gz * 0.999f - 1e-5f, 0.f);
+            const float gzs = fmaxf(gz * 0.999f - eps, 0.f);
             if (gzs * gzs > bd) continue;
             for (int cy = lo[1]; cy <= hi[1]; ++cy) {
                 const float gy = fmaxf(fmaxf(org[1] + (float)cy * h - y, y - (org[1] + (float)(cy + 1) * h)), 0.f);
-                const float gys = fmaxf(gy * 0.999f - 1e-5f, 0.f);
+                const float gys = fmaxf(gy * 0.999f - eps, 0.f);
                 const float dyz = gzs * gzs + gys * gys;
                 if (dyz > bd) continue;
                 // cells of one (cz,cy) row are consecutive => their points form ONE contiguous range of `sorted`.
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
                 if (row_in_prev) { seg_hi[0] = pl[0] - 1; seg_lo[1] = ph[0] + 1; seg_hi[1] = hi[0]; }
                 int xlo = lo[0], xhi = hi[0];
                 if (bd < 3.0e38f) {                                 // x extent of the ball of radius sqrt(bd) at this row, inflated
-                    const float rx = sqrtf(bd - dyz) * 1.001f + 2e-5f;
+                    const float rx = sqrtf(bd - dyz) * 1.001f + 2.f * eps;
                     xlo = max(xlo, (int)floorf(fmaxf((x - rx - org[0]) * ih, -1.f)));
                     xhi = min(xhi, (int)floorf(fminf((x + rx - org[0]) * ih, 1.0e6f)));
                 }
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
         }
         if (db >= 3.0e38f) done = true;                            // the whole grid has been visited
         else {
-            const float dbe = db * 0.999f - 1e-5f;                 // points sit in their cell up to fp32 rounding
+            const float dbe = db * 0.999f - eps;                 // points sit in their cell up to fp32 rounding
             if (dbe > 0.f && bd < dbe * dbe) done = true;
         }
 #pragma unroll
@@ -398,6 +403,7 @@ __global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, 
         const unsigned int i = unresolved[u];
         const float x = p1[(int64_t)i * 3], y = p1[(int64_t)i * 3 + 1], z = p1[(int64_t)i * 3 + 2];
         const float q[3] = {x, y, z};
+        const float eps = gi->eps + 2e-6f * fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
         int cq[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) cq[c] = cell_coord(q[c], org[c], ih, dims[c]);
@@ -420,10 +426,10 @@ __global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, 
                 if (best != 0xFFFFFFFFFFFFFFFFull) {           // same exact ball pruning as the per-lane pass
                     const float gz = fmaxf(fmaxf(org[2] + (float)cz * h - z, z - (org[2] + (float)(cz + 1) * h)), 0.f);
                     const float gy = fmaxf(fmaxf(org[1] + (float)cy * h - y, y - (org[1] + (float)(cy + 1) * h)), 0.f);
-                    const float gzs = fmaxf(gz * 0.999f - 1e-5f, 0.f), gys = fmaxf(gy * 0.999f - 1e-5f, 0.f);
+                    const float gzs = fmaxf(gz * 0.999f - eps, 0.f), gys = fmaxf(gy * 0.999f - eps, 0.f);
                     const float dyz = gzs * gzs + gys * gys;
                     if (dyz > bd0) continue;
-                    const float rx = sqrtf(bd0 - dyz) * 1.001f + 2e-5f;
+                    const float rx = sqrtf(bd0 - dyz) * 1.001f + 2.f * eps;
                     xlo = max(xlo, (int)floorf(fmaxf((x - rx - org[0]) * ih, -1.f)));
                     xhi = min(xhi, (int)floorf(fminf((x + rx - org[0]) * ih, 1.0e6f)));
                 }
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, 
             }
             if (db >= 3.0e38f) break;                          // the whole grid has been visited
             const float bd = __uint_as_float((unsigned int)(best >> 32));
-            const float dbe = db * 0.999f - 1e-5f;
+            const float dbe = db * 0.999f - eps;
             if (best != 0xFFFFFFFFFFFFFFFFull && dbe > 0.f && bd < dbe * dbe) break;
 #pragma unroll
             for (int c = 0; c < 3; ++c) { pl[c] = lo[c]; ph[c] = hi[c]; }

@@ -194,7 +194,7 @@ def test_knn_full_frame_properties():
     assert torch.equal(d[:2000].cpu(), dr) and torch.equal(i[:2000].cpu(), ir)
 
 
-@pytest.mark.parametrize("case", ["surface", "clustered", "far_queries", "degenerate", "big_map", "sparse_far"])
+@pytest.mark.parametrize("case", ["surface", "clustered", "far_queries", "degenerate", "big_map", "sparse_far", "large_coordinates"])
 def test_knn_grid_equals_brute(case):
     """The grid search must return exactly what the brute force returns (distances AND indices, ties included) on
     surface-like data, heavy clusters with duplicates, queries far outside the reference set, and a degenerate cloud."""
@@ -222,6 +222,14 @@ def test_knn_grid_equals_brute(case):
         near = torch.stack([v[:, 0], 1.2 * torch.cos(v[:, 1]) + 0.01, v[:, 1]], 1)
         far = torch.rand(10000, 3, generator=g) * torch.tensor([20.0, 6.0, 20.0]) - torch.tensor([10.0, 3.0, 10.0])
         q = torch.cat([near, far, ref[11:12], ref[5100:5101]], 0)
+    elif case == "large_coordinates":   # a dense sheet 300 m from the origin: fp32 ulp there is 3e-5 m, several times the cell-face
+        n = 200000                          # slack a fixed 1e-5 m margin would give; queries both near the sheet and 2 km away
+        u = torch.rand(n, 2, generator=g) * 6
+        ref = torch.stack([300.0 + u[:, 0], -200.0 + 0.3 * torch.sin(u[:, 0]) + 0.001 * torch.randn(n, generator=g), 150.0 + u[:, 1]], 1)
+        v = torch.rand(30000, 2, generator=g) * 6
+        near = torch.stack([300.0 + v[:, 0], -200.0 + 0.3 * torch.sin(v[:, 0]) + 0.004, 150.0 + v[:, 1]], 1)
+        far = torch.rand(2000, 3, generator=g) * 4000 - 2000
+        q = torch.cat([near, far], 0)
     elif case == "sparse_far":     # tiny clusters far apart: the finishing pass has to double its radius through empty space
         ref = torch.cat([0.01 * torch.randn(6000, 3, generator=g), 0.01 * torch.randn(6000, 3, generator=g) + 30.0], 0)
         q = torch.cat([torch.rand(4000, 3, generator=g) * 30, 0.01 * torch.randn(500, 3, generator=g) + 30.0], 0)
