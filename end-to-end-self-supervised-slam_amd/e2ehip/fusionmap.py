@@ -6,7 +6,7 @@ import math
 import torch
 
 from . import _lib as L
-from .ops import fusion_alpha_den, vertex_normal_maps
+from .ops import vertex_normal_maps
 
 
 class FusionMap:

@@ -1,6 +1,3 @@
-import torch
-
-from e2ehip.fusionmap import FusionMap
 from ..structures import Pointclouds
 from .icpslam import ICPSLAM
 

@@ -1,6 +1,5 @@
 """CPU-side checks of the C-ABI boundary: the library loads without a GPU and exports every symbol
 include/e2eslam.h declares; the ctypes table covers the same set; CPU tensors are refused."""
-import ctypes
 import os
 import re
 

@@ -3,7 +3,6 @@
 import numpy as np
 import pytest
 import torch
-import torch.nn.functional as F
 
 from oracle import depthnet, knn, pointfusion, poses, refine, warp_loss
 

@@ -1,12 +1,11 @@
 #!/usr/bin/env python3
 """Per-layer timing of the depth network's convolutions (B=2, 480x640 input): native kernels vs the MIOpen scaffold.
     python tools/conv_bench.py            (on an MI355X)"""
-import os, sys, time
+import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "end-to-end-self-supervised-slam_amd")]
-from e2ehip import conv, nn_ops
-import torch.nn.functional as F
+from e2ehip import nn_ops
 
 DEV = "cuda:0"
 # name, Cx, Cskip, up, H, W (of the conv's full-res input), Cout, k, s, p, pad_mode, act
