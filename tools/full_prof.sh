@@ -5,6 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/fullprof_$1; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats -d /tmp/fp_$1 -o full --output-format csv -- python3 bench.py --workload full --no-cpu-baseline --steps $1 --warmup $2 > $OUT/bench.log 2>&1
 f=$(find /tmp/fp_$1 -name "*kernel_stats.csv" | head -1)
+cp "$f" $OUT/kernel_stats.csv
 python3 - "$f" > $OUT/summary.txt <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
