@@ -249,16 +249,21 @@ __global__ void k_metrics_final(const float* __restrict__ partials, int nparts, 
 // fused Adam on a flat fp32 buffer (torch.optim.Adam, amsgrad off, weight_decay 0):
 //   m = m + (1-b1)(g - m) ; v = b2 v + (1-b2) g g ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 // ---------------------------------------------------------------------------------------------
+// `participants` (device scalar or NULL): the gradient bucket holds the SUM over the data-parallel ranks and this is how
+// many of them contributed (it travels as an extra element of the same all-reduce); g / max(participants, 1) is the mean
+// -- the division rides in this kernel instead of a separate pass over the 57 MB bucket.  NULL or 1: g unchanged.
 __global__ __launch_bounds__(DT) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                              int64_t n, float one_minus_b1, float b2, float one_minus_b2, float step_size,
-                                             float bc2_sqrt, float eps) {
+                                             float bc2_sqrt, float eps, const float* __restrict__ participants) {
     const int64_t n4 = n >> 2;
+    const float cnt = participants ? fmaxf(participants[0], 1.f) : 1.f;
     float4* p4 = (float4*)p; const float4* g4 = (const float4*)g; float4* m4 = (float4*)m; float4* v4 = (float4*)v;
     for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * DT) {
         float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
         float* pa = (float*)&pp; float* ga = (float*)&gg; float* ma = (float*)&mm; float* va = (float*)&vv;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            ga[k] = ga[k] / cnt;
             ma[k] = ma[k] + one_minus_b1 * (ga[k] - ma[k]);
             va[k] = va[k] * b2 + one_minus_b2 * (ga[k] * ga[k]);
             const float den = sqrtf(va[k]) / bc2_sqrt + eps;
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(DT) void k_adam(float* __restrict__ p, const float*
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
     }
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * DT + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT) {
-        const float gi = g[i];
+        const float gi = g[i] / cnt;
         const float mi = m[i] + one_minus_b1 * (gi - m[i]);
         const float vi = v[i] * b2 + one_minus_b2 * (gi * gi);
         m[i] = mi; v[i] = vi;
@@ -369,8 +374,21 @@ int e2e_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     hipLaunchKernelGGL(k_adam, dim3(sgrid(n >> 2 > 0 ? n >> 2 : 1, 2048)), dim3(DT), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, n, 1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2_sqrt, eps);
+                       exp_avg_sq, n, 1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2_sqrt, eps, (const float*)nullptr);
     E2E_LAUNCH_CHECK("e2e_adam_step");
+    return E2E_OK;
+}
+
+int e2e_adam_step_mean(float* params, const float* grad_sums, const float* participants, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, int step, void* stream) {
+    E2E_REQUIRE(n > 0 && params && grad_sums && participants && exp_avg && exp_avg_sq && step >= 1, E2E_ERR_ARG, "e2e_adam_step_mean: bad argument");
+    E2E_REQUIRE(((uintptr_t)params | (uintptr_t)grad_sums | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0, E2E_ERR_ARG,
+                "e2e_adam_step_mean: buffers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(k_adam, dim3(sgrid(n >> 2 > 0 ? n >> 2 : 1, 2048)), dim3(DT), 0, (hipStream_t)stream, params, grad_sums, exp_avg,
+                       exp_avg_sq, n, 1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2_sqrt, eps, participants);
+    E2E_LAUNCH_CHECK("e2e_adam_step_mean");
     return E2E_OK;
 }
 

@@ -1,0 +1,253 @@
+// nn_misc.hip -- the non-GEMM layers of the depth network for gfx950 (all NHWC, HBM-bound streaming kernels):
+//   * 3x3 / stride 2 / pad 1 max-pool of the ResNet stem, forward and INDEX-FREE backward (every input element
+//     re-derives the arg-max of the <= 4 windows that contain it and gathers their gradients: no index tensor, no
+//     atomics)                                                          -- networks.py:53 (encoder.maxpool)
+//   * eval-mode BatchNorm whose affine parameters still train (the reference freezes parameters by the substring
+//     "bn", so `downsample.1` stays trainable: online_adaption.py:182-184): fold (gamma, beta, running stats) ->
+//     (scale, shift); y = z * scale + shift; d gamma / d beta by a two-stage fixed-order reduction
+//   * the same affine with C = 1 is Conv1x1(1, 1, bias) / ScaleLayer of the scale-learning experiments
+//     (networks.py:191-215, absolute_scale.py:207-240)
+//   * nearest x2 upsample + channel concat (the stand-alone `upsample()` helper, networks.py:218-221)
+#include "e2e_common.h"
+
+#include <math.h>
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+static inline int mgrid(int64_t n, int cap = 4096) {
+    int64_t g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// max-pool 3x3 / 2 / pad 1.  torch scans the window row-major and keeps the FIRST maximum (`val > maxval || isnan(val)`),
+// so ties -- frequent behind a ReLU -- send the gradient to the first maximal element; the backward below re-derives
+// exactly that choice.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int window_argmax(const float* __restrict__ xb, int H, int W, int C, int oh, int ow, int c, float& best) {
+    int arg = -1;
+    best = -INFINITY;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int y = 2 * oh - 1 + kh;
+        if (y < 0 || y >= H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int x = 2 * ow - 1 + kw;
+            if (x < 0 || x >= W) continue;
+            const float v = xb[((int64_t)y * W + x) * C + c];
+            if (arg < 0) arg = y * W + x;                      // ATen starts at the window's first valid element
+            if (v > best || v != v) { best = v; arg = y * W + x; }
+        }
+    }
+    return arg;
+}
+
+__global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {
+    const int64_t total = (int64_t)B * Ho * Wo * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t t = i;
+        const int c = (int)(t % C); t /= C;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho); t /= Ho;
+        const int b = (int)t;
+        float best;
+        window_argmax(x + (int64_t)b * H * W * C, H, W, C, oh, ow, c, best);
+        y[i] = best;
+    }
+}
+
+// dx[b,y,x,c] = sum over the windows (oh,ow) that contain (y,x) and whose first maximum sits at (y,x) of dy[b,oh,ow,c];
+// accumulate != 0 adds to dx instead of overwriting it (the stem output also feeds the decoder's last skip connection)
+__global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int B,
+                                                     int H, int W, int C, int Ho, int Wo, int accumulate) {
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t t = i;
+        const int c = (int)(t % C); t /= C;
+        const int xx = (int)(t % W); t /= W;
+        const int yy = (int)(t % H); t /= H;
+        const int b = (int)t;
+        const float* xb = x + (int64_t)b * H * W * C;
+        float g = 0.f;
+        // windows containing yy: 2*oh - 1 <= yy <= 2*oh + 1
+        const int oh0 = yy >> 1, oh1 = (yy + 1) >> 1, ow0 = xx >> 1, ow1 = (xx + 1) >> 1;
+        for (int oh = oh0; oh <= oh1; ++oh) {
+            if (oh >= Ho) continue;
+            for (int ow = ow0; ow <= ow1; ++ow) {
+                if (ow >= Wo) continue;
+                float best;
+                if (window_argmax(xb, H, W, C, oh, ow, c, best) == yy * W + xx) g += dy[(((int64_t)b * Ho + oh) * Wo + ow) * C + c];
+            }
+        }
+        dx[i] = accumulate ? dx[i] + g : g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// per-channel affine of an eval-mode BatchNorm with trainable gamma / beta
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bn_fold(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                                                 const float* __restrict__ var, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                 float* __restrict__ rstd, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float r = 1.f / sqrtf(var[c] + eps);              // torch: weight / sqrt(running_var + eps)
+    const float s = gamma[c] * r;
+    scale[c] = s;
+    shift[c] = beta[c] - mean[c] * s;
+    if (rstd) rstd[c] = r;
+}
+
+__global__ __launch_bounds__(256) void k_affine_fwd(const float* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    float* __restrict__ y, int64_t n, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        y[i] = fmaf(z[i], scale[c], shift ? shift[c] : 0.f);
+    }
+}
+
+// stage 1: block (cx, s) sums channels [64 cx, 64 cx + 64) over pixel slice s; thread = (channel lane, 1 of 4 pixel lanes)
+// d gamma[c] = sum_p dy[p,c] * (z[p,c] - mean[c]) * rstd[c],  d beta[c] = sum_p dy[p,c]     (mean / rstd NULL: 0 / 1)
+__global__ __launch_bounds__(256) void k_affine_bwd_partial(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, int64_t P, int C, int64_t pix_per_slice,
+                                                            float* __restrict__ partial /*[S][2][C]*/) {
+    __shared__ float sg[4][64], sb[4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int64_t p0 = (int64_t)blockIdx.y * pix_per_slice, p1 = (p0 + pix_per_slice < P) ? p0 + pix_per_slice : P;
+    float ag = 0.f, ab = 0.f;
+    if (c < C) {
+        const float m = mean ? mean[c] : 0.f, r = rstd ? rstd[c] : 1.f;
+        for (int64_t p = p0 + pl; p < p1; p += 4) {
+            const float g = dy[p * C + c];
+            ag = fmaf(g, (z[p * C + c] - m) * r, ag);
+            ab += g;
+        }
+    }
+    sg[pl][cl] = ag;
+    sb[pl][cl] = ab;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        float* o = partial + (int64_t)blockIdx.y * 2 * C;
+        o[c] = ((sg[0][cl] + sg[1][cl]) + sg[2][cl]) + sg[3][cl];
+        o[C + c] = ((sb[0][cl] + sb[1][cl]) + sb[2][cl]) + sb[3][cl];
+    }
+}
+
+// C == 1 (scale layer): a flat reduction, one partial pair per workgroup
+__global__ __launch_bounds__(256) void k_affine_bwd_partial1(const float* __restrict__ dy, const float* __restrict__ z, int64_t P,
+                                                             float* __restrict__ partial /*[S][2]*/) {
+    __shared__ float red[4];
+    float ag = 0.f, ab = 0.f;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
+        const float g = dy[p];
+        ag = fmaf(g, z[p], ag);
+        ab += g;
+    }
+    const float a = block_sum(ag, red);
+    __syncthreads();
+    const float b = block_sum(ab, red);
+    if (threadIdx.x == 0) { partial[blockIdx.x * 2] = a; partial[blockIdx.x * 2 + 1] = b; }
+}
+
+// stage 2: fixed-order sum over the slices; accumulate != 0 adds to the gradient buffers (flat gradient bucket)
+__global__ __launch_bounds__(256) void k_affine_bwd_final(const float* __restrict__ partial, int S, int C, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float g = 0.f, b = 0.f;
+    for (int s = 0; s < S; ++s) {
+        g += partial[(int64_t)s * 2 * C + c];
+        b += partial[(int64_t)s * 2 * C + C + c];
+    }
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + g : g;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + b : b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// nearest x2 upsample of x (B,h,w,C1) [+ concat skip (B,2h,2w,C2)] -> (B,2h,2w,C1+C2)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_upsample2_concat(const float* __restrict__ x, const float* __restrict__ skip, float* __restrict__ y, int B,
+                                                          int h, int w, int C1, int C2) {
+    const int H = 2 * h, W = 2 * w, C = C1 + C2;
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t t = i;
+        const int c = (int)(t % C); t /= C;
+        const int xx = (int)(t % W); t /= W;
+        const int yy = (int)(t % H); t /= H;
+        const int b = (int)t;
+        y[i] = (c < C1) ? x[(((int64_t)b * h + (yy >> 1)) * w + (xx >> 1)) * C1 + c]
+                        : skip[(((int64_t)b * H + yy) * W + xx) * C2 + (c - C1)];
+    }
+}
+
+#define AFF_SLICES 64
+
+extern "C" {
+
+int e2e_maxpool3x3s2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    E2E_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0, E2E_ERR_ARG, "e2e_maxpool3x3s2_fwd: bad argument");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(k_maxpool_fwd, dim3(mgrid((int64_t)B * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C, Ho, Wo);
+    E2E_LAUNCH_CHECK("e2e_maxpool3x3s2_fwd");
+    return E2E_OK;
+}
+
+int e2e_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int accumulate, void* stream) {
+    E2E_REQUIRE(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0, E2E_ERR_ARG, "e2e_maxpool3x3s2_bwd: bad argument");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3(mgrid((int64_t)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, B, H, W, C, Ho, Wo,
+                       accumulate);
+    E2E_LAUNCH_CHECK("e2e_maxpool3x3s2_bwd");
+    return E2E_OK;
+}
+
+int e2e_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale,
+                float* shift, float* rstd, int C, void* stream) {
+    E2E_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, E2E_ERR_ARG, "e2e_bn_fold: bad argument");
+    hipLaunchKernelGGL(k_bn_fold, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, scale,
+                       shift, rstd, C);
+    E2E_LAUNCH_CHECK("e2e_bn_fold");
+    return E2E_OK;
+}
+
+int e2e_affine_fwd(const float* z, const float* scale, const float* shift, float* y, int64_t n, int C, void* stream) {
+    E2E_REQUIRE(z && scale && y && n > 0 && C > 0 && n % C == 0, E2E_ERR_ARG, "e2e_affine_fwd: bad argument");
+    hipLaunchKernelGGL(k_affine_fwd, dim3(mgrid(n)), dim3(256), 0, (hipStream_t)stream, z, scale, shift, y, n, C);
+    E2E_LAUNCH_CHECK("e2e_affine_fwd");
+    return E2E_OK;
+}
+
+int64_t e2e_affine_bwd_workspace_floats(int C) { return (int64_t)AFF_SLICES * 2 * (C > 0 ? C : 1); }
+
+int e2e_affine_bwd(const float* dy, const float* z, const float* mean, const float* rstd, int64_t P, int C, float* dgamma, float* dbeta,
+                   int accumulate, float* workspace, void* stream) {
+    E2E_REQUIRE(dy && z && workspace && P > 0 && C > 0 && (dgamma || dbeta), E2E_ERR_ARG, "e2e_affine_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    int S = AFF_SLICES;
+    if (C == 1) {
+        E2E_REQUIRE(!mean && !rstd, E2E_ERR_ARG, "e2e_affine_bwd: the single-channel form takes no statistics");
+        if ((P + 255) / 256 < S) S = (int)((P + 255) / 256);
+        hipLaunchKernelGGL(k_affine_bwd_partial1, dim3(S), dim3(256), 0, st, dy, z, P, workspace);
+    } else {
+        int64_t pps = (P + S - 1) / S;
+        if (pps < 4) pps = 4;
+        S = (int)((P + pps - 1) / pps);
+        hipLaunchKernelGGL(k_affine_bwd_partial, dim3((C + 63) / 64, S), dim3(256), 0, st, dy, z, mean, rstd, P, C, pps, workspace);
+    }
+    hipLaunchKernelGGL(k_affine_bwd_final, dim3((C + 255) / 256), dim3(256), 0, st, workspace, S, C, dgamma, dbeta, accumulate);
+    E2E_LAUNCH_CHECK("e2e_affine_bwd");
+    return E2E_OK;
+}
+
+int e2e_upsample2_concat(const float* x, const float* skip, float* y, int B, int h, int w, int C1, int C2, void* stream) {
+    E2E_REQUIRE(x && y && B > 0 && h > 0 && w > 0 && C1 > 0 && C2 >= 0 && (C2 == 0 || skip), E2E_ERR_ARG, "e2e_upsample2_concat: bad argument");
+    hipLaunchKernelGGL(k_upsample2_concat, dim3(mgrid((int64_t)B * 4 * h * w * (C1 + C2))), dim3(256), 0, (hipStream_t)stream, x, skip, y, B, h, w,
+                       C1, C2);
+    E2E_LAUNCH_CHECK("e2e_upsample2_concat");
+    return E2E_OK;
+}
+
+}  // extern "C"

@@ -23,20 +23,21 @@ def _bn_args(bn):
 
 
 class _ConvBN(nn.Module):
-    """Helper used by the ResNet body: conv (no bias) + BatchNorm2d [+ ReLU]; in training mode BN falls back to
-    torch's batch-statistics path (the refinement path always runs BN in eval mode: online_adaption.py:175-184)."""
+    """Helper used by the ResNet body: conv (no bias) + eval-mode BatchNorm2d [+ residual] [+ ReLU] in ONE launch."""
 
     @staticmethod
     def run(conv, bn, x, relu, residual=None, in_norm=None):
-        """relu?( BN(conv(x)) + residual? ).  BN is folded into the convolution's epilogue when it is a constant
-        (eval mode AND frozen parameters: the refinement mode freezes every parameter whose name contains "bn",
-        online_adaption.py:182-184); a BatchNorm that still trains (the `downsample.1` ones) or runs on batch
-        statistics keeps torch's op so that its parameters receive their gradients."""
-        if bn.training or bn.weight.requires_grad or bn.bias.requires_grad:
-            y = bn(nn_ops.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0], in_norm=in_norm))
-            if residual is not None:
-                y = y + residual
-            return torch.relu(y) if relu else y
+        """relu?( BN(conv(x)) + residual? ).  A frozen BatchNorm (the refinement mode freezes every parameter whose name
+        contains "bn", online_adaption.py:182-184) is folded into the convolution's epilogue as constants; one whose
+        affine still trains (the `downsample.1` ones) runs e2ehip's affine kernel behind the convolution so that gamma / beta
+        receive their gradients.  Batch-statistics (train-mode) BatchNorm is not on the refinement path: the reference
+        switches every module to eval() before refining (online_adaption.py:175-184, train_depth.py:198-207)."""
+        if bn.training:
+            raise NotImplementedError("train-mode BatchNorm (batch statistics) is not on the refinement path: call .eval() "
+                                      "(set_refinement_mode / set_eval) as the reference does before refining")
+        trainable = bn.weight.requires_grad or bn.bias.requires_grad
+        if trainable and (relu or residual is not None or in_norm is not None):
+            raise NotImplementedError("a trainable eval-mode BatchNorm is fused only behind a plain convolution (downsample branch)")
         return nn_ops.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0], "zeros", "relu" if relu else None, _bn_args(bn),
                              residual=residual, in_norm=in_norm)
 
@@ -208,7 +209,7 @@ class ScaleLayer(nn.Module):
         self.scale = nn.Parameter(torch.tensor([init_value]))
 
     def forward(self, x):
-        return x * self.scale
+        return nn_ops.scale_layer(x, self.scale)
 
 
 def upsample(x):
@@ -276,6 +277,16 @@ class DispResNet_Indoor(nn.Module):
 
     def init_weights(self):
         pass
+
+    def used_parameters(self):
+        """The parameters that take part in forward(): everything except the classifier `encoder.encoder.fc` and the three
+        dispconvs of the unused scales (networks.py:271-272 allocates four, :289-290 evaluates scale 0 only) -- these never
+        receive a gradient."""
+        skip = {id(p) for p in self.encoder.encoder.fc.parameters()}
+        for s in self.decoder.scales:
+            if s != 0:
+                skip |= {id(p) for p in self.decoder.convs[("dispconv", s)].parameters()}
+        return [p for p in self.parameters() if id(p) not in skip]
 
     def forward(self, x, index):
         return self.decoder(self.encoder(x), index)

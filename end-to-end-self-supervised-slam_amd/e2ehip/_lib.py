@@ -72,6 +72,7 @@ SIGNATURES = {
     "e2e_mean_diff_bwd": [c_fp, c_fp, c_fp, c_i64, c_int, c_fp, c_fp],
     "e2e_depth_metrics": [c_fp, c_fp, c_i64, c_int, c_fp, c_fp, c_fp],
     "e2e_adam_step": [c_fp, c_fp, c_fp, c_fp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_fp],
+    "e2e_adam_step_mean": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_fp],
     "e2e_aux_workspace_floats": [],
     "e2e_smoothness_lossgrad": [c_fp, c_fp, Strides, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
     "e2e_geometric_consistency_lossgrad": [c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp],
@@ -88,6 +89,13 @@ SIGNATURES = {
     "e2e_conv2d_gather_adjoint": [c_fp] + [c_int] * 7 + [c_fp, c_fp, c_int, c_int, c_fp],
     "e2e_conv2d_wgrad_workspace_floats": [c_int] * 8,
     "e2e_conv2d_bwd_weight": [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp] + [c_int] * 13 + [c_f32, c_f32, c_fp],
+    "e2e_maxpool3x3s2_fwd": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp],
+    "e2e_maxpool3x3s2_bwd": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp],
+    "e2e_bn_fold": [c_fp, c_fp, c_fp, c_fp, c_f32, c_fp, c_fp, c_fp, c_int, c_fp],
+    "e2e_affine_fwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_fp],
+    "e2e_affine_bwd_workspace_floats": [c_int],
+    "e2e_affine_bwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_fp, c_fp, c_int, c_fp, c_fp],
+    "e2e_upsample2_concat": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp],
     "e2e_head_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp],
     "e2e_head_workspace_floats": [],
     "e2e_head_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp],
@@ -99,7 +107,8 @@ _RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats"
             "e2e_knn1_workspace_bytes": c_i64, "e2e_median_workspace_bytes": c_i64,
             "e2e_depth_scale_workspace_bytes": c_i64, "e2e_reduce_workspace_floats": c_i64,
             "e2e_conv2d_wgrad_workspace_floats": c_i64, "e2e_conv2d_splitk_workspace_floats": c_i64,
-            "e2e_head_workspace_floats": c_i64, "e2e_icp_workspace_bytes": c_i64, "e2e_aux_workspace_floats": c_i64}
+            "e2e_head_workspace_floats": c_i64, "e2e_icp_workspace_bytes": c_i64, "e2e_aux_workspace_floats": c_i64,
+            "e2e_affine_bwd_workspace_floats": c_i64}
 
 _lib = None
 
@@ -120,9 +129,13 @@ def load():
     return _lib
 
 
+PROFILE_HOOK = [None]           # e2ehip.profile.KernelTimer while a timing pass is active
+
+
 def call(name, *args):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    hook = PROFILE_HOOK[0]
+    rc = getattr(lib, name)(*args) if hook is None else hook.around(name, args, lambda: getattr(lib, name)(*args))
     if rc != 0:
         raise E2EError(f"{name} failed ({rc}): {lib.e2e_last_error().decode()}")
 

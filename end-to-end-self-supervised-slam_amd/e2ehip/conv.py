@@ -131,8 +131,138 @@ def available():
 
 
 def supports(weight):
-    """Layer shapes the native kernels cover: Cout a multiple of 16 (MFMA path) or the 16 -> 1 3x3 disparity head."""
-    return weight.shape[0] % 16 == 0 or tuple(weight.shape) == (1, 16, 3, 3)
+    """Layer shapes the native kernels cover: Cout a multiple of 16 (MFMA path), the 16 -> 1 3x3 disparity head and the
+    1 -> 1 1x1 scale layer (Conv1x1(1, 1) of the scale-learning experiments)."""
+    return weight.shape[0] % 16 == 0 or tuple(weight.shape) in ((1, 16, 3, 3), (1, 1, 1, 1))
+
+
+def _grad_out(param, shape):
+    """(buffer, accumulate): the parameter's slice of FusedAdam's flat gradient buffer inside direct_weight_grads(),
+    else a fresh tensor that is returned to autograd."""
+    s = _sink(param, shape)
+    return (s, 1) if s is not None else (torch.empty(shape, device=param.device, dtype=torch.float32), 0)
+
+
+class _Affine(torch.autograd.Function):
+    """y[..., c] = z[..., c] * scale[c] + shift[c] on NHWC memory, with the gradients of the parameters the scale / shift
+    come from.  mode "bn": scale = gamma / sqrt(var + eps), shift = beta - mean * scale (an eval-mode BatchNorm whose
+    affine still trains: online_adaption.py:182-184 leaves `downsample.1` trainable); mode "conv1": C = 1, scale = the
+    (1,1,1,1) weight and shift = the bias of Conv1x1(1, 1) (networks.py:191-204)."""
+
+    @staticmethod
+    def forward(ctx, z, p_scale, p_shift, mean, var, eps):
+        z = L.dev(z, "input")
+        C = z.shape[1]
+        z = _cl(z)
+        dev, st = z.device, L.stream()
+        bn = mean is not None
+        if bn:
+            scale, shift, rstd = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(3))
+            L.call("e2e_bn_fold", L.ptr(p_scale), L.ptr(p_shift), L.ptr(mean), L.ptr(var), float(eps), L.ptr(scale), L.ptr(shift), L.ptr(rstd), C, st)
+        else:
+            if C != 1:
+                raise NotImplementedError("the plain affine form is the single-channel scale layer")
+            scale, shift, rstd = p_scale.reshape(1), (p_shift.reshape(1) if p_shift is not None else None), None
+        y = torch.empty_like(z)
+        L.call("e2e_affine_fwd", L.ptr(z), L.ptr(scale), L.ptr(shift), L.ptr(y), z.numel(), C, st)
+        ctx.save_for_backward(z, scale, mean, rstd)
+        ctx.params = (p_scale, p_shift)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        z, scale, mean, rstd = ctx.saved_tensors
+        p_scale, p_shift = ctx.params
+        C = z.shape[1]
+        g = _cl(g)
+        st = L.stream()
+        gs = gb = None
+        acc = 0
+        want_s, want_b = ctx.needs_input_grad[1], (p_shift is not None and ctx.needs_input_grad[2])
+        if want_s or want_b:
+            ss = _sink(p_scale, p_scale.shape) if want_s else None
+            sb = _sink(p_shift, p_shift.shape) if want_b else None
+            direct = (ss is not None or not want_s) and (sb is not None or not want_b)
+            acc = 1 if direct else 0
+            gs = (ss if direct else torch.empty(p_scale.shape, device=g.device, dtype=torch.float32)) if want_s else None
+            gb = (sb if direct else torch.empty(p_shift.shape, device=g.device, dtype=torch.float32)) if want_b else None
+            ws = torch.empty(L.load().e2e_affine_bwd_workspace_floats(C), device=g.device, dtype=torch.float32)
+            L.call("e2e_affine_bwd", L.ptr(g), L.ptr(z), L.ptr(mean), L.ptr(rstd), z.numel() // C, C, L.ptr(gs), L.ptr(gb), acc, L.ptr(ws), st)
+            if direct:
+                gs = gb = None
+        dz = None
+        if ctx.needs_input_grad[0]:
+            dz = torch.empty_like(g)
+            L.call("e2e_conv2d_act_bwd", L.ptr(g), L.ptr(g), L.ptr(scale), L.ptr(dz), g.numel(), C, 0, st)
+        return dz, gs, gb, None, None, None
+
+
+def conv2d_bn_affine(x, weight, bn, stride, padding, pad_mode, residual=None):
+    """BN_eval_with_trainable_affine(conv(x)): the convolution writes its raw output, the affine is its own small kernel so
+    that gamma / beta get exact gradients from the stored convolution output (these tensors are tiny: the three 1x1
+    stride-2 `downsample` branches of ResNet-18)."""
+    if residual is not None:
+        raise NotImplementedError("residual add behind a trainable BatchNorm is not used by the network")
+    w, b, rm, rv, eps = bn
+    z = conv2d(x, weight, None, stride, padding, pad_mode)
+    return _Affine.apply(z, w, b, rm, rv, eps)
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl(L.dev(x, "input"))
+        B, C, H, W = x.shape
+        y = torch.empty(B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device=x.device, dtype=torch.float32, memory_format=CL)
+        L.call("e2e_maxpool3x3s2_fwd", L.ptr(x), L.ptr(y), B, H, W, C, L.stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = _cl(g)
+        dx = torch.empty_like(x)
+        L.call("e2e_maxpool3x3s2_bwd", L.ptr(x), L.ptr(g), L.ptr(dx), B, H, W, C, 0, L.stream())
+        return dx
+
+
+def max_pool_3x3_s2(x):
+    return _MaxPool.apply(x)
+
+
+class _Upsample2Concat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, skip):
+        x = _cl(L.dev(x, "input"))
+        B, C1, h, w = x.shape
+        C2 = 0
+        if skip is not None:
+            skip = _cl(L.dev(skip, "skip"))
+            C2 = skip.shape[1]
+            if tuple(skip.shape) != (B, C2, 2 * h, 2 * w):
+                raise ValueError(f"skip tensor: expected {(B, C2, 2 * h, 2 * w)}, got {tuple(skip.shape)}")
+        y = torch.empty(B, C1 + C2, 2 * h, 2 * w, device=x.device, dtype=torch.float32, memory_format=CL)
+        L.call("e2e_upsample2_concat", L.ptr(x), L.ptr(skip), L.ptr(y), B, h, w, C1, C2, L.stream())
+        ctx.dims = (B, h, w, C1, C2)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        B, h, w, C1, C2 = ctx.dims
+        g = _cl(g)
+        g0 = torch.empty(B, C1, h, w, device=g.device, dtype=torch.float32, memory_format=CL)
+        g1 = torch.empty(B, C2, 2 * h, 2 * w, device=g.device, dtype=torch.float32, memory_format=CL) if C2 else None
+        L.call("e2e_conv2d_gather_adjoint", L.ptr(g), B, 2 * h, 2 * w, C1 + C2, C1, 2, 0, L.ptr(g0), L.ptr(g1), 0, 0, L.stream())
+        return g0, g1
+
+
+def upsample2_concat(x, skip=None):
+    return _Upsample2Concat.apply(x, skip)
 
 
 class _Head(torch.autograd.Function):
@@ -295,6 +425,11 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, pad_mode="zeros", act=None
     bn_scale_shift: (scale, shift) per output channel (folded eval-mode BatchNorm; constants, no gradient)."""
     if pad_mode not in ("zeros", "reflect"):
         raise ValueError(f"pad_mode {pad_mode}")
+    if tuple(weight.shape) == (1, 1, 1, 1):
+        if stride != 1 or padding != 0 or skip is not None or upsample != 1 or residual is not None or bn_scale_shift is not None \
+                or act is not None or in_norm is not None:
+            raise NotImplementedError("the 1 -> 1 convolution is the plain scale layer (Conv1x1(1, 1))")
+        return _Affine.apply(x, weight, bias, None, None, 0.0)
     if weight.shape[0] == 1:
         if tuple(weight.shape) != (1, 16, 3, 3) or pad_mode != "reflect" or padding != 1 or stride != 1 or skip is not None \
                 or upsample != 1 or residual is not None or bn_scale_shift is not None:

@@ -2,7 +2,8 @@
 
 The path shards by SEQUENCE: every rank refines its own keyframe pairs against its own global map; the only
 exchange per refinement step is the depth network's gradient, which FusedAdam keeps as ONE contiguous fp32
-bucket (14 319 409 trainable elements = 57.3 MB), so the step is a single all-reduce with no flatten copies.
+bucket (14 319 409 trainable elements = 57.3 MB, plus a tail element that counts the participating ranks), so the step
+is a single all-reduce with no flatten copies.
 At the end of a run the per-rank maps are gathered (variable length)."""
 import torch
 import torch.distributed as dist
@@ -12,19 +13,42 @@ def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def exchange_gradients_(flat, participating=True):
+    """The ONE collective of a refinement step (between loss.backward() and optimizer.step(), online_adaption.py:539-540):
+    all-reduce(SUM) of FusedAdam's flat gradient bucket.  Keyframe decisions are data dependent (online_adaption.py:234), so a
+    rank without a keyframe joins with a zero bucket; the number of contributing ranks rides in the bucket's tail element
+    (`flat.grad_ext` = gradients + one 16-byte tail), so it is summed by the SAME all-reduce, and FusedAdam divides by it
+    inside the Adam kernel (e2e_adam_step_mean) -- no second collective, no separate division pass.
+    `flat`: e2ehip.optim.FlatParams.  world size 1: nothing to do (participants stays 1)."""
+    if not participating:
+        flat.grad_ext.zero_()
+    flat.grad_ext[flat.numel] = 1.0 if participating else 0.0
+    if world() > 1:
+        dist.all_reduce(flat.grad_ext, op=dist.ReduceOp.SUM)
+    return flat.grad_ext[flat.numel:flat.numel + 1]
+
+
 def allreduce_mean_(flat_grad, participating=True):
-    """In-place average of the flat gradient bucket over the ranks that took a refinement step this round.
-    Keyframe decisions are data dependent (online_adaption.py:234), so a rank without a keyframe joins with a
-    zero bucket and the sum is divided by the number of participants (all-reduced alongside, one extra float)."""
+    """Stand-alone form for a bare tensor: in-place mean over the participating ranks (bucket and count in ONE all-reduce
+    through a temporary with a tail element).  The driver uses exchange_gradients_ on the resident bucket instead."""
     if world() == 1:
         return flat_grad
-    if not participating:
-        flat_grad.zero_()
-    cnt = torch.tensor([1.0 if participating else 0.0], device=flat_grad.device)
-    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
-    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    flat_grad.div_(cnt.clamp(min=1.0))
+    ext = torch.empty(flat_grad.numel() + 1, device=flat_grad.device, dtype=flat_grad.dtype)
+    ext[:-1] = flat_grad.reshape(-1) if participating else 0.0
+    ext[-1] = 1.0 if participating else 0.0
+    dist.all_reduce(ext, op=dist.ReduceOp.SUM)
+    flat_grad.copy_((ext[:-1] / ext[-1].clamp(min=1.0)).view_as(flat_grad))
     return flat_grad
+
+
+def common_rounds(n_local, device):
+    """Every rank must join the same number of gradient exchanges: the number of keyframe rounds of a run is the maximum
+    over the ranks (ranks with fewer keyframes idle through the surplus rounds as non-participants)."""
+    if world() == 1:
+        return int(n_local)
+    t = torch.tensor([int(n_local)], device=device, dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
 
 
 def gather_maps(points, normals, colors, ccounts):

@@ -21,7 +21,10 @@ class FlatParams:
             total += (p.numel() + 3) // 4 * 4            # keep every slice 16-byte aligned
         self.params, self.offsets, self.numel = params, offs, total
         self.data = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        # gradients + a 16-byte tail whose first element counts the ranks that contributed to the bucket (dist.exchange_gradients_)
+        self.grad_ext = torch.zeros(total + 4, device=dev, dtype=torch.float32)
+        self.grad = self.grad_ext[:total]
+        self.grad_ext[total] = 1.0
         with torch.no_grad():
             for p, o in zip(params, offs):
                 self.data[o:o + p.numel()].copy_(p.reshape(-1))
@@ -38,6 +41,9 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
         self.bind_grads()
+
+    def participants(self):
+        return self.grad_ext[self.numel:self.numel + 1]
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -67,6 +73,19 @@ class FusedAdam(torch.optim.Optimizer):
         self.m = torch.zeros_like(self.flat.data)
         self.v = torch.zeros_like(self.flat.data)
 
+    def prebuild(self, params):
+        """Fix the flat layout before the first backward (data-parallel runs: a rank may have to join a gradient exchange
+        before its own first keyframe).  `params`: the parameters that will receive gradients, in a rank-independent order."""
+        if self.flat is not None:
+            return
+        known = {id(p) for p in self._all}
+        act = [p for p in params if p.requires_grad and id(p) in known]
+        if not act:
+            raise RuntimeError("FusedAdam.prebuild(): no trainable parameter")
+        self.flat = FlatParams(act)
+        self.m = torch.zeros_like(self.flat.data)
+        self.v = torch.zeros_like(self.flat.data)
+
     def zero_grad(self, set_to_none=True):
         if self.flat is None:
             for p in self._all:
@@ -82,5 +101,6 @@ class FusedAdam(torch.optim.Optimizer):
         self.steps += 1
         from . import conv
         conv.WEIGHT_EPOCH[0] += 1                      # the kernel rewrites the weights behind torch's version counters
-        L.call("e2e_adam_step", L.ptr(self.flat.data), L.ptr(self.flat.grad), L.ptr(self.m), L.ptr(self.v), self.flat.numel,
-               float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self.steps, L.stream())
+        # the bucket holds the SUM over the data-parallel ranks and its tail the number of contributors (1 on a single GPU)
+        L.call("e2e_adam_step_mean", L.ptr(self.flat.data), L.ptr(self.flat.grad), L.ptr(self.flat.participants()), L.ptr(self.m), L.ptr(self.v),
+               self.flat.numel, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self.steps, L.stream())

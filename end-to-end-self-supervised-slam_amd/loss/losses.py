@@ -2,8 +2,8 @@
 
 SSIM / photometric_loss / knn_points_loss run in hand-written HIP kernels; the small auxiliary losses
 that are off by default in the reference's configuration (smoothness, geometric consistency, sparse
-ground-truth loss: configs/config.yaml:45-52) and the printed metrics are thin compositions whose
-reductions run through e2ehip as well where a kernel exists.
+ground-truth loss: configs/config.yaml:45-52), the depth regulariser and the printed metrics are one fused launch each
+(csrc/aux_losses.hip, csrc/depth_ops.hip).
 """
 import torch
 import torch.nn as nn
@@ -62,12 +62,12 @@ def disparity_smoothness_loss(disp, img):
 
 
 def depth_reguralizer(initial_depth, refined_depth, loss_func):
-    """reference: losses.py:134-148 (the reference's spelling is kept)."""
-    if loss_func == "l1":
-        return torch.mean(torch.abs(initial_depth - refined_depth))
-    if loss_func == "l2":
-        return torch.mean((initial_depth - refined_depth) ** 2)
-    raise ValueError("please specify a correct norm")
+    """reference: losses.py:134-148 (the reference's spelling is kept): nn.L1Loss / nn.MSELoss between the stored initial
+    depth and the refined one -- e2e_mean_diff_fwd/bwd (fixed-order reduction; the gradient flows to `refined_depth`, the
+    initial depth is a detached clone: online_adaption.py:284-285)."""
+    if loss_func not in ("l1", "l2"):
+        raise ValueError("please specify a correct norm")
+    return ops.mean_diff(initial_depth.detach(), refined_depth, loss_func)
 
 
 def depth_gt_loss(prediction, sparse_groundtruth, sparse_mask):
@@ -88,24 +88,14 @@ def process_disparity(disp_pair):
 
 @torch.no_grad()
 def depth_metrics(dataset, gt, pred):
-    """reference: losses.py:162-181 -> abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3 (0-dim tensors)."""
-    pred, gt = pred.squeeze().detach(), gt.squeeze().detach()
-    if dataset == "TUM":
-        keep = gt != 0.0
-    elif dataset == "ICL":
-        keep = torch.ones_like(gt, dtype=torch.bool)
-    else:
+    """reference: losses.py:162-181 -> abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3 (0-dim tensors); one e2e_depth_metrics
+    launch, the TUM zero-depth holes are masked inside the kernel (losses.py:167-169)."""
+    if dataset not in ("TUM", "ICL"):
         raise ValueError("Dataset Not Found")
-    return compute_depth_errors(gt[keep], pred[keep])
+    return tuple(ops.depth_metrics(gt.squeeze().detach(), pred.squeeze().detach(), dataset == "TUM").unbind(0))
 
 
 @torch.no_grad()
 def compute_depth_errors(gt, pred):
-    """reference: losses.py:183-201."""
-    thresh = torch.max(gt / pred, pred / gt)
-    a1, a2, a3 = ((thresh < 1.25 ** k).float().mean() for k in (1, 2, 3))
-    rmse = torch.sqrt(((gt - pred) ** 2).mean())
-    rmse_log = torch.sqrt(((torch.log(gt) - torch.log(pred)) ** 2).mean())
-    abs_rel = torch.mean(torch.abs(gt - pred) / gt)
-    sq_rel = torch.mean((gt - pred) ** 2 / gt)
-    return abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3
+    """reference: losses.py:183-201 on already-selected 1-D tensors (every element counts)."""
+    return tuple(ops.depth_metrics(gt.detach(), pred.detach(), False).unbind(0))

@@ -51,6 +51,9 @@ class SLAM:
         self.model_init()
         self.mean_abs = []
         self.log = []
+        self.refinement_steps_done = 0
+        # backward-weight chains on a second stream next to backward-data (bench.py's per-kernel timing pass switches it off)
+        self.overlap_wgrad = os.environ.get("E2E_WGRAD_OVERLAP", "1") == "1"
 
     # ------------------------------------------------------------------------------------------------
     def dataset_init(self):
@@ -124,21 +127,46 @@ class SLAM:
         return torch.linalg.norm(pc - cc)
 
     # ------------------------------------------------------------------------------------------------
+    def keyframe_schedule(self):
+        """[(previous keyframe, new keyframe)] decided once on the host -- poses are dataset inputs, not results, so the
+        reference's per-frame device sync (`if dist > threshold`, online_adaption.py:231-234) is not needed."""
+        poses_h = self.poses.cpu()
+        prev, out = 0, []
+        for frame in range(1, self.sequence_length):
+            if self.compute_frame_distance(poses_h[:, prev], poses_h[:, frame]) > self.args.DEMO.frame_threshold:
+                out.append((prev, frame))
+                prev = frame
+        return out
+
     def main(self):
         if self.args.MODEL.refinement_mode:
             self.set_refinement_mode()
-        prev = 0
         self.first_iter = True
-        # keyframe schedule decided once on the host (poses are data, not results): no device sync per frame
-        poses_h = self.poses.cpu()
-        for frame in range(1, self.sequence_length):
-            if self.compute_frame_distance(poses_h[:, prev], poses_h[:, frame]) > self.args.DEMO.frame_threshold:
-                self.refinement(prev, frame)
+        schedule = self.keyframe_schedule()
+        # one sequence per rank (SURVEY.md 8e): every rank joins the same number of gradient exchanges; a rank whose
+        # sequence has fewer keyframes idles through the surplus rounds as a non-participant
+        rounds = edist.common_rounds(len(schedule), self.device)
+        if edist.world() > 1:
+            self.optimizer.prebuild(self.models["depth"].used_parameters())
+        for i in range(rounds):
+            if i < len(schedule):
+                self.refinement(*schedule[i])
                 self.first_iter = False
-                prev = frame
+            else:
+                self.idle_round()
         if self.args.DEBUG.print_metrics and self.mean_abs:
             print(torch.tensor(self.mean_abs).mean().item())
+        if edist.world() > 1:                   # end of run: variable-length gather of the per-rank maps (SURVEY.md 5.8 C2)
+            self.gathered_map = edist.gather_maps(*self.map.live())
         return self.map
+
+    def idle_round(self):
+        """A keyframe round of another rank: contribute a zero bucket to each of its gradient exchanges and apply the
+        same averaged update, so that the shared depth network stays identical on every rank."""
+        for _ in range(self.args.OPTIMIZATION.refinement_steps):
+            self.optimizer.zero_grad()
+            self._exchange_gradients(participating=False)
+            self.optimizer.step()
 
     def _pair(self, prev, cur):
         idx = torch.tensor([prev, cur], device=self.device)
@@ -147,7 +175,16 @@ class SLAM:
         poses = self.poses[:, idx]
         return colors, gt, poses
 
-    def refinement(self, prev, cur):
+    def reset_map(self):
+        """Start a new sequence pass with the current network: empty global map, first-keyframe rules apply again."""
+        self.map.M = 0
+        self.map._knn = None
+        self.first_iter = True
+        self.estimated_poses = []
+
+    def refinement(self, prev, cur, max_steps=None):
+        """One keyframe: `OPTIMIZATION.refinement_steps` optimisation steps on the pair (prev, cur), then the map update
+        (online_adaption.py:259-327).  max_steps (bench.py) truncates the optimisation loop to time an exact step count."""
         a = self.args
         colors, gt, poses = self._pair(prev, cur)
         transform = torch_poses_to_transforms(poses)
@@ -159,7 +196,8 @@ class SLAM:
         initial = None
         use_reg = a.LOSS.depth_regularizer and a.OPTIMIZATION.refinement == "PFT"
         use_3d = a.LOSS.three3d_loss and not self.first_iter
-        for refine_step in range(a.OPTIMIZATION.refinement_steps):
+        nsteps = a.OPTIMIZATION.refinement_steps if max_steps is None else min(int(max_steps), a.OPTIMIZATION.refinement_steps)
+        for refine_step in range(nsteps):
             self.optimizer.zero_grad()
             disp = self.models["depth"](colors[0], 0)[("disp", 0, 0)]                     # (2,1,H,W): pair as one batch
             depth, delta, ratio = ops.depth_from_disp_median_scaled(disp, median_gt)
@@ -178,10 +216,11 @@ class SLAM:
                 l3 = self.compute_3d_loss(d_tgt, K, poses[:, 1], T)
                 roots.append(l3 * a.LOSS.three3d_loss_weight)
                 grads.append(None)
-            with e2e_conv.direct_weight_grads(overlap=os.environ.get("E2E_WGRAD_OVERLAP", "1") == "1"):      # weight gradients accumulate straight into FusedAdam's flat bucket
+            with e2e_conv.direct_weight_grads(overlap=self.overlap_wgrad):      # weight gradients accumulate straight into FusedAdam's flat bucket
                 torch.autograd.backward(roots, grads)
             self._exchange_gradients()
             self.optimizer.step()
+            self.refinement_steps_done += 1
             if a.DEBUG.print_metrics:
                 m = ops.depth_metrics(gt[0, 1], d_tgt.detach(), a.DATA.name == "TUM")
                 total = loss2[0] + (a.LOSS.depth_regularizer_weight * loss2[1] if use_reg else 0.0)
@@ -191,7 +230,7 @@ class SLAM:
                 self.log.append(rec)
                 print("Refine_Step:", refine_step, "Total_Loss:", round(rec[0].item(), 5), "abs_rel: ", round(rec[4].item(), 5),
                       "rmse: ", round(rec[6].item(), 5), "a1: ", round(rec[8].item(), 5))
-                if refine_step == a.OPTIMIZATION.refinement_steps - 1:
+                if refine_step == nsteps - 1:
                     self.mean_abs.append(rec[4].item())
         self.create_refined_pointcloud(colors, gt, poses, median_gt)
 
@@ -205,11 +244,12 @@ class SLAM:
         d, _ = ops.knn1(moved, self.map.knn_index(self.H * self.W))    # one grid build per keyframe, three queries
         return d.mean()
 
-    def _exchange_gradients(self):
+    def _exchange_gradients(self, participating=True):
+        """between loss.backward() and optimizer.step() (online_adaption.py:539-540): ONE all-reduce of the flat bucket."""
         if edist.world() > 1:
             if self.optimizer.flat is None:
                 self.optimizer._build()
-            edist.allreduce_mean_(self.optimizer.flat.grad)
+            edist.exchange_gradients_(self.optimizer.flat, participating)
 
     @torch.no_grad()
     def create_refined_pointcloud(self, colors, gt, poses, median_gt):

@@ -295,6 +295,13 @@ int e2e_depth_metrics(const float* gt, const float* pred, int64_t n, int mask_ze
  * 16-byte-aligned fp32 buffer per state; `step` is the 1-based step count. */
 int e2e_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, int step, void* stream);
+/* The data-parallel form (one sequence per GPU): `grad_sums` is the flat bucket after ONE all-reduce(SUM)
+ * over the ranks, `participants` (device scalar, all-reduced as the bucket's extra tail element) the number of ranks that
+ * took a refinement step; the update uses grad_sums / max(participants, 1).  participants == 1: identical to
+ * e2e_adam_step. */
+int e2e_adam_step_mean(float* params, const float* grad_sums, const float* participants, float* exp_avg,
+                       float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                       int step, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Depth network convolutions -- depth_estimation/networks.py:44-57,157-189,277-292             */
@@ -353,6 +360,34 @@ int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1,
                           float* dw, float* dbias, float* workspace, int B, int Hs, int Ws, int Cin,
                           int Cout, int Ho, int Wo, int KH, int KW, int stride, int pad,
                           int pad_mode, int accumulate, float in_sub, float in_mul, void* stream);
+
+/* ResNet stem max-pool, nn.MaxPool2d(3, 2, 1) (networks.py:53 -> torchvision resnet.maxpool): x (B,H,W,C) NHWC ->
+ * y (B,(H-1)/2+1,(W-1)/2+1,C).  The backward keeps no index tensor: every input element re-derives the first maximum
+ * (ATen's scan order) of the <= 4 windows that contain it; accumulate != 0 adds to dx. */
+int e2e_maxpool3x3s2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+int e2e_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C,
+                         int accumulate, void* stream);
+
+/* eval-mode BatchNorm with a TRAINABLE affine (the reference freezes parameters whose name contains "bn",
+ * online_adaption.py:182-184, so encoder.layerN.0.downsample.1 keeps training): scale = gamma / sqrt(var + eps),
+ * shift = beta - mean * scale, rstd = 1 / sqrt(var + eps) (rstd may be NULL). */
+int e2e_bn_fold(const float* gamma, const float* beta, const float* running_mean,
+                const float* running_var, float eps, float* scale, float* shift, float* rstd, int C,
+                void* stream);
+/* y[i] = z[i] * scale[i % C] + shift[i % C] over n NHWC elements (shift may be NULL).  With C = 1 this is
+ * Conv1x1(1, 1, bias) / ScaleLayer of the scale-learning experiments (networks.py:191-215). */
+int e2e_affine_fwd(const float* z, const float* scale, const float* shift, float* y, int64_t n, int C,
+                   void* stream);
+int64_t e2e_affine_bwd_workspace_floats(int C);
+/* d gamma[c] = sum_p dy[p,c] (z[p,c] - mean[c]) rstd[c], d beta[c] = sum_p dy[p,c] over P pixels (mean / rstd NULL:
+ * 0 / 1, required for C = 1); two-stage fixed-order reduction; accumulate != 0 adds to the outputs. */
+int e2e_affine_bwd(const float* dy, const float* z, const float* mean, const float* rstd, int64_t P,
+                   int C, float* dgamma, float* dbeta, int accumulate, float* workspace, void* stream);
+
+/* upsample() of networks.py:218-221 [+ torch.cat with the skip tensor, :283-286]: x (B,h,w,C1), skip (B,2h,2w,C2) or
+ * NULL -> y (B,2h,2w,C1+C2), all NHWC.  (Inside the decoder this is fused into the next convolution's gather.) */
+int e2e_upsample2_concat(const float* x, const float* skip, float* y, int B, int h, int w, int C1,
+                         int C2, void* stream);
 
 /* The 1-channel disparity head: Conv3x3(reflect) 16 -> 1 (+ activation), networks.py:271-272,289-290.
  * x (B,H,W,16) NHWC, w (1,16,3,3), y (B,H,W).  Backward: dz = dY*act' (e2e_conv2d_act_bwd) ->

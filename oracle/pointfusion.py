@@ -140,14 +140,17 @@ def find_best_unique_correspondences(points, ccounts, maps, pc2im):
     d = points[n] - maps["Vg"][h, w]
     d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
     W = maps["Vg"].shape[1]
-    pix = (h * W + w).tolist()
-    best = {}
-    for i, p in enumerate(pix):
-        key = (float(inv_c[i]), float(d2[i]), int(n[i]))
-        if p not in best or key < best[p][0]:
-            best[p] = (key, i)
-    rows = [best[p][1] for p in sorted(best)]
-    return pc2im[torch.tensor(rows, dtype=torch.int64)]
+    pix = h * W + w
+    # lexicographic minimum of (1/c, d2, n) per pixel == first row of each pixel's run after a row-lexicographic sort by
+    # (pixel, 1/c, d2, n) (gradslam: torch.unique(rows, dim=0)); built from stable sorts, least significant key first
+    # (rows arrive in ascending n, so n is already in order)
+    order = torch.arange(pix.shape[0])
+    for key in (d2, inv_c, pix):
+        order = order[torch.sort(key[order], stable=True).indices]
+    ps = pix[order]
+    first = torch.ones_like(ps, dtype=torch.bool)
+    first[1:] = ps[1:] != ps[:-1]
+    return pc2im[order[first]]
 
 
 def fusion_alpha(V, sigma, eps=1e-7):

@@ -5,7 +5,23 @@ import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "end-to-end-self-supervised-slam_amd")]
+import torch.nn.functional as F
 from e2ehip import nn_ops
+
+
+def torch_conv(x, weight, bias, stride, padding, pad_mode, act, skip, upsample, in_norm):
+    """The torch / MIOpen composition of the same layer: the A/B reference of this tool only (never imported by the package)."""
+    if in_norm is not None:
+        x = (x - in_norm[0]) * in_norm[1]
+    if upsample != 1:
+        x = F.interpolate(x, scale_factor=upsample, mode="nearest")
+    if skip is not None:
+        x = torch.cat([x, skip], 1)
+    if pad_mode == "reflect" and padding:
+        x = F.pad(x, (padding,) * 4, mode="reflect")
+        padding = 0
+    y = F.conv2d(x, weight, bias, stride, padding)
+    return F.relu(y) if act == "relu" else (F.elu(y) if act == "elu" else y)
 
 DEV = "cuda:0"
 # name, Cx, Cskip, up, H, W (of the conv's full-res input), Cout, k, s, p, pad_mode, act
@@ -62,8 +78,10 @@ def main():
                 t.requires_grad_(not (stem and t is x))
         res = {}
         for backend in ("hip", "miopen"):
-            nn_ops.BACKEND = backend
-            f = lambda: nn_ops.conv2d(x, w, bias, s, p, pm, act, None, None, skip, up, (0.45, 4.44) if stem else None)
+            if backend == "hip":
+                f = lambda: nn_ops.conv2d(x, w, bias, s, p, pm, act, None, None, skip, up, (0.45, 4.44) if stem else None)
+            else:
+                f = lambda: torch_conv(x, w, bias, s, p, pm, act, skip, up, (0.45, 4.44) if stem else None)
             tf = timeit(lambda: f())
             y = f()
             gy = torch.randn_like(y)
