@@ -100,10 +100,12 @@ __global__ __launch_bounds__(256) void k_bn_fold(const float* __restrict__ gamma
 }
 
 __global__ __launch_bounds__(256) void k_affine_fwd(const float* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                    float* __restrict__ y, int64_t n, int C) {
+                                                    const float* __restrict__ res, int relu, float* __restrict__ y, int64_t n, int C) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % C);
-        y[i] = fmaf(z[i], scale[c], shift ? shift[c] : 0.f);
+        float v = fmaf(z[i], scale[c], shift ? shift[c] : 0.f);
+        if (res) v += res[i];
+        y[i] = relu ? fmaxf(v, 0.f) : v;
     }
 }
 
@@ -213,9 +215,10 @@ int e2e_bn_fold(const float* gamma, const float* beta, const float* running_mean
     return E2E_OK;
 }
 
-int e2e_affine_fwd(const float* z, const float* scale, const float* shift, float* y, int64_t n, int C, void* stream) {
+int e2e_affine_fwd(const float* z, const float* scale, const float* shift, const float* residual, int relu, float* y, int64_t n, int C,
+                   void* stream) {
     E2E_REQUIRE(z && scale && y && n > 0 && C > 0 && n % C == 0, E2E_ERR_ARG, "e2e_affine_fwd: bad argument");
-    hipLaunchKernelGGL(k_affine_fwd, dim3(mgrid(n)), dim3(256), 0, (hipStream_t)stream, z, scale, shift, y, n, C);
+    hipLaunchKernelGGL(k_affine_fwd, dim3(mgrid(n)), dim3(256), 0, (hipStream_t)stream, z, scale, shift, residual, relu, y, n, C);
     E2E_LAUNCH_CHECK("e2e_affine_fwd");
     return E2E_OK;
 }

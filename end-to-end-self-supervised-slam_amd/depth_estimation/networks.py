@@ -35,9 +35,6 @@ class _ConvBN(nn.Module):
         if bn.training:
             raise NotImplementedError("train-mode BatchNorm (batch statistics) is not on the refinement path: call .eval() "
                                       "(set_refinement_mode / set_eval) as the reference does before refining")
-        trainable = bn.weight.requires_grad or bn.bias.requires_grad
-        if trainable and (relu or residual is not None or in_norm is not None):
-            raise NotImplementedError("a trainable eval-mode BatchNorm is fused only behind a plain convolution (downsample branch)")
         return nn_ops.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0], "zeros", "relu" if relu else None, _bn_args(bn),
                              residual=residual, in_norm=in_norm)
 

@@ -144,69 +144,73 @@ def _grad_out(param, shape):
 
 
 class _Affine(torch.autograd.Function):
-    """y[..., c] = z[..., c] * scale[c] + shift[c] on NHWC memory, with the gradients of the parameters the scale / shift
-    come from.  mode "bn": scale = gamma / sqrt(var + eps), shift = beta - mean * scale (an eval-mode BatchNorm whose
-    affine still trains: online_adaption.py:182-184 leaves `downsample.1` trainable); mode "conv1": C = 1, scale = the
-    (1,1,1,1) weight and shift = the bias of Conv1x1(1, 1) (networks.py:191-204)."""
+    """y = relu?( z * scale[c] + shift[c] + residual ) on NHWC memory, with the gradients of the parameters the scale / shift
+    come from.  BN form (mean given): scale = gamma / sqrt(var + eps), shift = beta - mean * scale (an eval-mode BatchNorm
+    whose affine still trains: online_adaption.py:182-184 leaves `downsample.1` trainable; a network that was not put in
+    refinement mode trains every BatchNorm's affine).  Plain form: C = 1, scale = the (1,1,1,1) weight and shift = the bias
+    of Conv1x1(1, 1) / ScaleLayer (networks.py:191-215)."""
 
     @staticmethod
-    def forward(ctx, z, p_scale, p_shift, mean, var, eps):
+    def forward(ctx, z, p_scale, p_shift, mean, var, eps, residual, relu):
         z = L.dev(z, "input")
         C = z.shape[1]
         z = _cl(z)
         dev, st = z.device, L.stream()
-        bn = mean is not None
-        if bn:
+        if mean is not None:
             scale, shift, rstd = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(3))
             L.call("e2e_bn_fold", L.ptr(p_scale), L.ptr(p_shift), L.ptr(mean), L.ptr(var), float(eps), L.ptr(scale), L.ptr(shift), L.ptr(rstd), C, st)
         else:
             if C != 1:
                 raise NotImplementedError("the plain affine form is the single-channel scale layer")
             scale, shift, rstd = p_scale.reshape(1), (p_shift.reshape(1) if p_shift is not None else None), None
+        if residual is not None:
+            residual = _cl(L.dev(residual, "residual"))
         y = torch.empty_like(z)
-        L.call("e2e_affine_fwd", L.ptr(z), L.ptr(scale), L.ptr(shift), L.ptr(y), z.numel(), C, st)
-        ctx.save_for_backward(z, scale, mean, rstd)
+        L.call("e2e_affine_fwd", L.ptr(z), L.ptr(scale), L.ptr(shift), L.ptr(residual), int(bool(relu)), L.ptr(y), z.numel(), C, st)
+        ctx.save_for_backward(z, scale, mean, rstd, y if relu else None)
         ctx.params = (p_scale, p_shift)
+        ctx.has_res = residual is not None
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        z, scale, mean, rstd = ctx.saved_tensors
+        z, scale, mean, rstd, y = ctx.saved_tensors
         p_scale, p_shift = ctx.params
         C = z.shape[1]
         g = _cl(g)
         st = L.stream()
+        if y is not None:                            # dA = g * relu'(y)
+            dA = torch.empty_like(g)
+            L.call("e2e_conv2d_act_bwd", L.ptr(g), L.ptr(y), None, L.ptr(dA), g.numel(), C, ACT["relu"], st)
+            g = dA
         gs = gb = None
-        acc = 0
         want_s, want_b = ctx.needs_input_grad[1], (p_shift is not None and ctx.needs_input_grad[2])
         if want_s or want_b:
             ss = _sink(p_scale, p_scale.shape) if want_s else None
             sb = _sink(p_shift, p_shift.shape) if want_b else None
             direct = (ss is not None or not want_s) and (sb is not None or not want_b)
-            acc = 1 if direct else 0
             gs = (ss if direct else torch.empty(p_scale.shape, device=g.device, dtype=torch.float32)) if want_s else None
             gb = (sb if direct else torch.empty(p_shift.shape, device=g.device, dtype=torch.float32)) if want_b else None
             ws = torch.empty(L.load().e2e_affine_bwd_workspace_floats(C), device=g.device, dtype=torch.float32)
-            L.call("e2e_affine_bwd", L.ptr(g), L.ptr(z), L.ptr(mean), L.ptr(rstd), z.numel() // C, C, L.ptr(gs), L.ptr(gb), acc, L.ptr(ws), st)
+            L.call("e2e_affine_bwd", L.ptr(g), L.ptr(z), L.ptr(mean), L.ptr(rstd), z.numel() // C, C, L.ptr(gs), L.ptr(gb), 1 if direct else 0,
+                   L.ptr(ws), st)
             if direct:
                 gs = gb = None
         dz = None
         if ctx.needs_input_grad[0]:
             dz = torch.empty_like(g)
             L.call("e2e_conv2d_act_bwd", L.ptr(g), L.ptr(g), L.ptr(scale), L.ptr(dz), g.numel(), C, 0, st)
-        return dz, gs, gb, None, None, None
+        return dz, gs, gb, None, None, None, (g if ctx.has_res else None), None
 
 
-def conv2d_bn_affine(x, weight, bn, stride, padding, pad_mode, residual=None):
-    """BN_eval_with_trainable_affine(conv(x)): the convolution writes its raw output, the affine is its own small kernel so
-    that gamma / beta get exact gradients from the stored convolution output (these tensors are tiny: the three 1x1
-    stride-2 `downsample` branches of ResNet-18)."""
-    if residual is not None:
-        raise NotImplementedError("residual add behind a trainable BatchNorm is not used by the network")
+def conv2d_bn_affine(x, weight, bn, stride, padding, pad_mode, residual=None, relu=False, in_norm=None):
+    """relu?( BN_eval_with_trainable_affine(conv(x)) + residual ): the convolution writes its raw output, the affine is its own
+    small kernel so that gamma / beta get exact gradients from the stored convolution output.  On the refinement path these
+    are the three tiny 1x1 stride-2 `downsample` branches of ResNet-18 (every other BatchNorm is frozen and folded)."""
     w, b, rm, rv, eps = bn
-    z = conv2d(x, weight, None, stride, padding, pad_mode)
-    return _Affine.apply(z, w, b, rm, rv, eps)
+    z = conv2d(x, weight, None, stride, padding, pad_mode, in_norm=in_norm)
+    return _Affine.apply(z, w, b, rm, rv, eps, residual, bool(relu))
 
 
 class _MaxPool(torch.autograd.Function):
@@ -429,7 +433,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, pad_mode="zeros", act=None
         if stride != 1 or padding != 0 or skip is not None or upsample != 1 or residual is not None or bn_scale_shift is not None \
                 or act is not None or in_norm is not None:
             raise NotImplementedError("the 1 -> 1 convolution is the plain scale layer (Conv1x1(1, 1))")
-        return _Affine.apply(x, weight, bias, None, None, 0.0)
+        return _Affine.apply(x, weight, bias, None, None, 0.0, None, False)
     if weight.shape[0] == 1:
         if tuple(weight.shape) != (1, 16, 3, 3) or pad_mode != "reflect" or padding != 1 or stride != 1 or skip is not None \
                 or upsample != 1 or residual is not None or bn_scale_shift is not None:

@@ -45,9 +45,9 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, pad_mode="zeros", act=None
         raise NotImplementedError(f"convolution weight {tuple(weight.shape)}: the native kernels cover Cout % 16 == 0, the 16 -> 1 3x3 "
                                   "reflect disparity head and the 1 -> 1 1x1 scale layer; there is no library fallback")
     if bn is not None and (bn[0].requires_grad or bn[1].requires_grad):
-        if bias is not None or act is not None or skip is not None or upsample != 1 or in_norm is not None:
-            raise NotImplementedError("a trainable eval-mode BatchNorm is only fused behind a plain convolution (downsample.1)")
-        return conv.conv2d_bn_affine(x, weight, bn, stride, padding, pad_mode, residual)
+        if bias is not None or act not in (None, "relu") or skip is not None or upsample != 1:
+            raise NotImplementedError("a trainable eval-mode BatchNorm follows a plain convolution (ResNet body) only")
+        return conv.conv2d_bn_affine(x, weight, bn, stride, padding, pad_mode, residual, act == "relu", in_norm)
     return conv.conv2d(x, weight, bias, stride, padding, pad_mode, act, _fold_bn(bn) if bn is not None else None, residual, skip,
                        upsample, in_norm)
 
@@ -70,4 +70,4 @@ def scale_layer(x, scale):
     _require_device(x)
     if x.dim() != 4 or x.shape[1] != 1 or scale.numel() != 1:
         raise NotImplementedError("ScaleLayer is applied to a (B,1,H,W) depth / disparity map with a single scale")
-    return conv._Affine.apply(x, scale, None, None, None, 0.0)
+    return conv._Affine.apply(x, scale, None, None, None, 0.0, None, False)

@@ -374,10 +374,11 @@ int e2e_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int 
 int e2e_bn_fold(const float* gamma, const float* beta, const float* running_mean,
                 const float* running_var, float eps, float* scale, float* shift, float* rstd, int C,
                 void* stream);
-/* y[i] = z[i] * scale[i % C] + shift[i % C] over n NHWC elements (shift may be NULL).  With C = 1 this is
- * Conv1x1(1, 1, bias) / ScaleLayer of the scale-learning experiments (networks.py:191-215). */
-int e2e_affine_fwd(const float* z, const float* scale, const float* shift, float* y, int64_t n, int C,
-                   void* stream);
+/* y[i] = relu?( z[i] * scale[i % C] + shift[i % C] + residual[i] ) over n NHWC elements (shift / residual may be NULL).
+ * With C = 1 and no residual / relu this is Conv1x1(1, 1, bias) / ScaleLayer of the scale-learning experiments
+ * (networks.py:191-215). */
+int e2e_affine_fwd(const float* z, const float* scale, const float* shift, const float* residual, int relu,
+                   float* y, int64_t n, int C, void* stream);
 int64_t e2e_affine_bwd_workspace_floats(int C);
 /* d gamma[c] = sum_p dy[p,c] (z[p,c] - mean[c]) rstd[c], d beta[c] = sum_p dy[p,c] over P pixels (mean / rstd NULL:
  * 0 / 1, required for C = 1); two-stage fixed-order reduction; accumulate != 0 adds to the outputs. */
