@@ -207,7 +207,60 @@ __global__ __launch_bounds__(AT) void k_disp_blend_bwd(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// masked mean: loss = sum_i [gate_i != 0] v_i / #{gate_i != 0};  d loss / d v_i = weight [gate_i != 0] / count.
+// The 3-D point loss (online_adaption.py:638-645, losses.py:57-63) averages the nearest-neighbour distances of the pixels
+// with valid depth; the reference boolean-indexes those rows out (a dynamic shape and a host sync), here every pixel keeps
+// its row and the gate (the depth map itself) masks it.  in 8n (+ 4n for the gradient pass), out 4n
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AT) void k_masked_mean_partial(const float* __restrict__ v, const float* __restrict__ gate, int64_t n,
+                                                            float* __restrict__ partials) {
+    __shared__ float red[AT / 64];
+    float s = 0.f, c = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * AT + threadIdx.x; i < n; i += (int64_t)gridDim.x * AT) {
+        const bool on = gate[i] != 0.f;
+        s += on ? v[i] : 0.f;
+        c += on ? 1.f : 0.f;
+    }
+    const float t0 = block_sum(s, red);
+    __syncthreads();
+    const float t1 = block_sum(c, red);
+    if (threadIdx.x == 0) { partials[blockIdx.x] = t0; partials[gridDim.x + blockIdx.x] = t1; }
+}
+
+__global__ __launch_bounds__(64) void k_masked_mean_final(const float* __restrict__ partials, int nparts, float weight, float* __restrict__ out3) {
+    double acc[2];
+    for (int s = 0; s < 2; ++s) {
+        double v = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += 64) v += (double)partials[s * nparts + i];
+        acc[s] = wave_sum_d(v);
+    }
+    if (threadIdx.x == 0) {
+        out3[0] = acc[1] > 0.0 ? (float)(acc[0] / acc[1]) : (float)(0.0 / 0.0);     // mean of an empty selection is NaN, as in torch
+        out3[1] = (float)acc[1];
+        out3[2] = acc[1] > 0.0 ? (float)((double)weight / acc[1]) : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(AT) void k_masked_mean_grad(const float* __restrict__ gate, int64_t n, const float* __restrict__ out3,
+                                                         float* __restrict__ g) {
+    const float k = out3[2];
+    for (int64_t i = (int64_t)blockIdx.x * AT + threadIdx.x; i < n; i += (int64_t)gridDim.x * AT) g[i] = gate[i] != 0.f ? k : 0.f;
+}
+
 extern "C" {
+
+int e2e_masked_mean_lossgrad(const float* values, const float* gate, int64_t n, float weight, float* out3, float* g_values, float* workspace,
+                             void* stream) {
+    E2E_REQUIRE(values && gate && out3 && workspace && n > 0, E2E_ERR_ARG, "e2e_masked_mean_lossgrad: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int g = agrid(n);
+    hipLaunchKernelGGL(k_masked_mean_partial, dim3(g), dim3(AT), 0, st, values, gate, n, workspace);
+    hipLaunchKernelGGL(k_masked_mean_final, dim3(1), dim3(64), 0, st, workspace, g, weight, out3);
+    if (g_values) hipLaunchKernelGGL(k_masked_mean_grad, dim3(agrid(n, 2048)), dim3(AT), 0, st, gate, n, out3, g_values);
+    E2E_LAUNCH_CHECK("e2e_masked_mean_lossgrad");
+    return E2E_OK;
+}
 
 int64_t e2e_aux_workspace_floats(void) { return 2 * APARTS; }
 

@@ -48,6 +48,11 @@ struct ConvArgs {
     // k_conv_splitk_epilogue adds the slices in order and applies the epilogue.  ksplit == 1: direct epilogue.
     int ksplit, cps;
     float* slab;
+    // backward-data of a stride-2 convolution: the input-gradient pixels split into 4 parity classes (y & 1, x & 1); a pixel
+    // of class (py, px) only meets the taps with kh = (py + off) mod 2 (+2), kw likewise -- 1, 2, 2 and 4 of the 9 taps of a
+    // 3x3 kernel.  cls != 0: workgroup blockIdx.x handles tile blockIdx.x >> 2 of class blockIdx.x & 3 with that tap subset
+    // (the plain transposed gather walks all 9 taps for every pixel and finds 3/4 of them to be stride holes).
+    int cls;
     int64_t bytes0, bytes1, bytesw;   // extents of src0 / src1 / w for the buffer resources (< 2 GB each)
 };
 
@@ -105,10 +110,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     __shared__ float Bs[2][CB][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
-    const int64_t Ntot = (int64_t)a.B * a.Hd * a.Wd;
-    const int64_t n0 = (int64_t)blockIdx.x * BM;
+    // parity-class form (transposed gather, stride 2): this workgroup's class, its pixel sub-lattice and its tap subset
+    const bool CLS = TRANSPOSED && VEC == 4 && a.cls != 0;
+    const int py = CLS ? (int)((blockIdx.x >> 1) & 1) : 0, px = CLS ? (int)(blockIdx.x & 1) : 0;
+    const int Hc = CLS ? (a.Hd - py + 1) / 2 : a.Hd, Wc = CLS ? (a.Wd - px + 1) / 2 : a.Wd;
+    const int kh0 = CLS ? ((py + a.off) & 1) : 0, kw0 = CLS ? ((px + a.off) & 1) : 0, kstep = CLS ? 2 : 1;
+    const int nkh = CLS ? (a.KH - kh0 + 1) / 2 : a.KH, nkw = CLS ? (a.KW - kw0 + 1) / 2 : a.KW;
+    const int64_t Ntot = (int64_t)a.B * Hc * Wc;
+    const int64_t n0 = (int64_t)(CLS ? (blockIdx.x >> 2) : blockIdx.x) * BM;
+    if (CLS && (n0 >= Ntot || nkh <= 0 || nkw <= 0)) return;        // classes are sized by the largest one; empty tap sets write nothing (output pre-zeroed by the host for KH < 2)
     const int c0 = blockIdx.y * BN;
-    const int K = a.KH * a.KW * a.Cin;
+    const int K = CLS ? nkh * nkw * a.Cin : a.KH * a.KW * a.Cin;
     const int nchunks_all = (K + CB - 1) / CB;
     const int cbeg = (a.ksplit > 1) ? blockIdx.z * a.cps : 0;
     const int cend = (a.ksplit > 1) ? min(nchunks_all, cbeg + a.cps) : nchunks_all;
@@ -127,11 +139,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         arow_ok[j] = e < A_CNT && an < Ntot;
         ab[j] = ayd[j] = axd[j] = 0;
         if (arow_ok[j]) {
-            const int hw = a.Hd * a.Wd;
+            const int hw = Hc * Wc;
             ab[j] = (int)(an / hw);
             const int r = (int)(an - (int64_t)ab[j] * hw);
-            ayd[j] = r / a.Wd;
-            axd[j] = r - ayd[j] * a.Wd;
+            ayd[j] = r / Wc;
+            axd[j] = r - ayd[j] * Wc;
+            if (CLS) { ayd[j] = 2 * ayd[j] + py; axd[j] = 2 * axd[j] + px; }
         }
     }
     const int sh = a.up >> 1;                                // up is 1 or 2: source coordinate = full-res coordinate >> sh
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     int ld_kh = 0, ld_kw = 0, ld_cc = 0;                     // state of the LOAD stream (runs one chunk ahead)
     unsigned off0[A_PER], off1[A_PER];                       // byte offsets of (tap pixel, this thread's quad) in src0 / src1
     auto set_tap = [&]() {
-        const bool tap_ok = ld_kh < a.KH;
+        const bool tap_ok = ld_kh < a.KH;                  // (class form: kh walks kh0, kh0 + 2, ...)
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
             int ys = 0, xs = 0;
@@ -170,7 +183,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     };
     auto next_tap = [&]() {
         ld_cc = 0;
-        if (++ld_kw == a.KW) { ld_kw = 0; ++ld_kh; }
+        ld_kw += kstep;
+        if (ld_kw >= a.KW) { ld_kw = kw0; ld_kh += kstep; }
         set_tap();
     };
     unsigned boff[B_PER];                                    // B tile: fixed per-thread offset, the chunk rides in soffset
@@ -183,8 +197,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     }
     if (VEC == 4) {                                          // position the load stream on chunk `cbeg`
         const int t0 = cbeg / cpt;
-        ld_kh = t0 / a.KW;
-        ld_kw = t0 - ld_kh * a.KW;
+        ld_kh = kh0 + kstep * (t0 / nkw);
+        ld_kw = kw0 + kstep * (t0 - (t0 / nkw) * nkw);
         ld_cc = cbeg - t0 * cpt;
         set_tap();
     }
@@ -193,6 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         const int kbase = chunk * CB;
         if (VEC == 4) {
             const int cbase = ld_cc * CB;                    // wave-uniform: the whole chunk lies on one side of the concat split
+            const int krow = (ld_kh * a.KW + ld_kw) * a.Cin + cbase;      // first weight row of this chunk (== kbase outside the class form)
             const bool use0 = cbase < a.C1;
             const __amdgpu_buffer_rsrc_t rs = use0 ? rs0 : rs1;
             const int soff = (use0 ? cbase : cbase - a.C1) * 4;
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
             if (++ld_cc == cpt) next_tap();
 #pragma unroll
             for (int j = 0; j < B_PER; ++j)
-                breg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsw, boff[j], kbase * a.ldw * 4, 0));
+                breg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsw, boff[j], krow * a.ldw * 4, 0));
         } else {
 #pragma unroll
             for (int j = 0; j < A_PER; ++j) {
@@ -296,6 +311,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         return;
     }
     // ---- epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5) ----------------------------
+    // class form: GEMM row n = (b, yc, xc) of the class lattice -> output pixel (b, 2 yc + py, 2 xc + px); the two divisions per
+    // row are multiplications by ceil(2^32 / d) (exact for n * d < 2^32: n < 2^21 rows, d < 2^10)
+    const unsigned hw_c = (unsigned)(Hc * Wc), mg_hw = CLS ? (0xFFFFFFFFu / hw_c) + 1u : 0u, mg_w = CLS ? (0xFFFFFFFFu / (unsigned)Wc) + 1u : 0u;
 #pragma unroll
     for (int u = 0; u < TM; ++u)
 #pragma unroll
@@ -307,9 +325,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int64_t n = n0 + (wm * TM + u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 if (n >= Ntot) continue;
+                int64_t orow = n;
+                if (CLS) {
+                    const unsigned un = (unsigned)n, b = hw_c == 1u ? un : __umulhi(un, mg_hw), rem = un - b * hw_c;
+                    const unsigned yc = Wc == 1 ? rem : __umulhi(rem, mg_w), xc = rem - yc * (unsigned)Wc;
+                    orow = ((int64_t)b * a.Hd + 2 * yc + py) * a.Wd + 2 * xc + px;
+                }
                 float v = fmaf(acc[u][t][r], sc, sh);
-                if (a.res) v += a.res[n * a.Ncols + col];
-                a.out[n * a.Ncols + col] = apply_act(v, a.act);
+                if (a.res) v += a.res[orow * a.Ncols + col];
+                a.out[orow * a.Ncols + col] = apply_act(v, a.act);
             }
         }
 }
@@ -640,45 +664,47 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
     }
 }
 
-// fold groups of FOLD consecutive slabs into one (fixed order inside a group, groups stay in order): turns the serial
-// S-long sum of the final pass into a two-level tree with S/FOLD-fold more parallelism
-#define WG_FOLD 16
-__global__ __launch_bounds__(256) void k_slab_fold(const float* __restrict__ in, int S, int64_t slab_elems, float* __restrict__ out) {
-    const int groups = (S + WG_FOLD - 1) / WG_FOLD;
-    const int64_t total = slab_elems * groups;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int gq = (int)(i / slab_elems);
-        const int64_t e = i - (int64_t)gq * slab_elems;
-        float v[WG_FOLD];
-#pragma unroll
-        for (int j = 0; j < WG_FOLD; ++j) {
-            const int z = gq * WG_FOLD + j;
-            v[j] = (z < S) ? in[(int64_t)z * slab_elems + e] : 0.f;     // independent loads, issued together
-        }
-        float sacc = 0.f;
-#pragma unroll
-        for (int j = 0; j < WG_FOLD; ++j) sacc += v[j];
-        out[i] = sacc;
-    }
-}
-
-// sum the slabs in slice order; scatter to dW (Cout,Cin,KH,KW) [accumulating when beta = 1] and the bias gradient
+// sum the S slabs and scatter to dW (Cout,Cin,KH,KW) [accumulating when `accumulate`] and the bias gradient, in ONE launch:
+// a workgroup owns 64 consecutive output elements; its 4 waves sum the slabs z = w, w + 4, w + 8, ... (independent loads,
+// 8 in flight per lane) and the four partial sums are combined through LDS in the fixed order ((p0 + p1) + p2) + p3 --
+// bitwise reproducible.  (Round 1 ran this as k_slab_fold + k_wgrad_reduce: two launches and a second trip of the folded
+// slabs through HBM for every layer.)
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, int S, int Mpad, int Npad, int Cout, int Cin,
                                                       int KH, int KW, int has_bias, float* __restrict__ dw, float* __restrict__ dbias,
                                                       int accumulate) {
-    const int Kconv = KH * KW * Cin;
-    const int64_t total = (int64_t)Cout * (Kconv + (has_bias ? 1 : 0));
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int m = (int)(i / (Kconv + (has_bias ? 1 : 0))), n = (int)(i - (int64_t)m * (Kconv + (has_bias ? 1 : 0)));
-        float s = 0.f;
-        for (int z = 0; z < S; ++z) s += slabs[((int64_t)z * Mpad + m) * Npad + n];
-        if (n < Kconv) {
-            const int tap = n / Cin, ci = n - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
-            float* d = dw + (((int64_t)m * Cin + ci) * KH + kh) * KW + kw;
-            *d = accumulate ? *d + s : s;
-        } else if (dbias) {
-            dbias[m] = accumulate ? dbias[m] + s : s;
+    __shared__ float part[4][64];
+    const int Kconv = KH * KW * Cin, Ng = Kconv + (has_bias ? 1 : 0);
+    const int64_t total = (int64_t)Cout * Ng;
+    const int e = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t slab_elems = (int64_t)Mpad * Npad;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+        const int64_t i = base + e;
+        const bool on = i < total;
+        const int m = on ? (int)(i / Ng) : 0, n = on ? (int)(i - (int64_t)m * Ng) : 0;
+        const float* src = slabs + (int64_t)m * Npad + n;
+        float sacc = 0.f;
+        int z = w;
+        for (; z + 28 < S; z += 32) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = on ? src[(int64_t)(z + 4 * j) * slab_elems] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sacc += v[j];
         }
+        for (; z < S; z += 4) sacc += on ? src[(int64_t)z * slab_elems] : 0.f;
+        part[w][e] = sacc;
+        __syncthreads();
+        if (w == 0 && on) {
+            const float t = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+            if (n < Kconv) {
+                const int tap = n / Cin, ci = n - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
+                float* d = dw + (((int64_t)m * Cin + ci) * KH + kh) * KW + kw;
+                *d = accumulate ? *d + t : t;
+            } else if (dbias) {
+                dbias[m] = accumulate ? dbias[m] + t : t;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -753,9 +779,10 @@ __global__ __launch_bounds__(256) void k_weight_layouts_batched(const long long*
     }
 }
 
-// dZ = dY * act'(Y) * scale[c]     (Y = the activation's OUTPUT; ELU' = y+1 for y<=0; DISP' = (y-.01)(1-(y-.01)/10))
+// dZ (+)= dY * act'(Y) * scale[c]     (Y = the activation's OUTPUT; ELU' = y+1 for y<=0; DISP' = (y-.01)(1-(y-.01)/10));
+// accumulate != 0 adds to dz (a gradient that a second consumer contributes to, e.g. the residual branch of a BasicBlock)
 __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ scale,
-                                                 float* __restrict__ dz, int64_t n, int C, int act) {
+                                                 float* __restrict__ dz, int64_t n, int C, int act, int accumulate) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float g = dy[i];
         const float v = y[i];
@@ -763,7 +790,7 @@ __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ dy, c
         else if (act == ACT_ELU) g = v > 0.f ? g : g * (v + 1.f);
         else if (act == ACT_DISP) { const float s = (v - 0.01f) * 0.1f; g = g * 10.f * s * (1.f - s); }
         if (scale) g *= scale[i % C];
-        dz[i] = g;
+        dz[i] = accumulate ? dz[i] + g : g;
     }
 }
 
@@ -970,6 +997,19 @@ static void launch_gemm(ConvArgs a, int vec, float* workspace, hipStream_t st) {
     a.bytes0 = (int64_t)a.B * (a.Hs / a.up) * (a.Ws / a.up) * a.C1 * 4;
     a.bytes1 = (int64_t)a.B * a.Hs * a.Ws * (a.Cin - a.C1) * 4;
     a.bytesw = (int64_t)K * a.ldw * 4;
+    if (TR && a.cls) {
+        // 4 parity classes x the tiles of the largest class (ceil(Hd/2) x ceil(Wd/2) pixels per image); blockIdx.x & 3 = class
+        const int64_t Nc = (int64_t)a.B * ((a.Hd + 1) / 2) * ((a.Wd + 1) / 2);
+        a.ksplit = 1;
+        if (a.Ncols <= 32) {
+            dim3 g((unsigned)(4 * ((Nc + 127) / 128)), (unsigned)((a.Ncols + 31) / 32));
+            GEMM_LAUNCH(4, 1, 1, 1, g);
+        } else {
+            dim3 g((unsigned)(4 * ((Nc + 63) / 64)), (unsigned)((a.Ncols + 63) / 64));
+            GEMM_LAUNCH(2, 2, 1, 1, g);
+        }
+        return;
+    }
     if (S > 1) {
         const int nchunks = (K + cb - 1) / cb;
         a.cps = (nchunks + S - 1) / S;
@@ -1057,8 +1097,8 @@ int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const f
     return E2E_OK;
 }
 
-int e2e_conv2d_bwd_data(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout,
-                        int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, float* workspace, void* stream) {
+static int bwd_data_impl(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout, int Ho, int Wo,
+                         int KH, int KW, int stride, int pad, int pad_mode, int accumulate, float* workspace, void* stream) {
     E2E_REQUIRE(dz && w_bwd && dxp && B > 0 && Cin > 0 && Cout > 0 && Cout % 16 == 0, E2E_ERR_ARG, "e2e_conv2d_bwd_data: bad argument (Cout %% 16 == 0)");
     E2E_REQUIRE(ld_bwd % 4 == 0 && ld_bwd >= Cin && (stride == 1 || stride == 2), E2E_ERR_ARG, "e2e_conv2d_bwd_data: bad sizes");
     E2E_REQUIRE((int64_t)B * Ho * Wo * Cout * 4 < (1ll << 31) && (int64_t)KH * KW * Cout * ld_bwd * 4 < (1ll << 31), E2E_ERR_ARG,
@@ -1069,9 +1109,27 @@ int e2e_conv2d_bwd_data(const float* dz, const float* w_bwd, int ld_bwd, float* 
     const int pp = pad_mode == 1 ? pad : 0;                // reflect: produce the whole padded domain, folded afterwards
     a.Hd = Hs + 2 * pp; a.Wd = Ws + 2 * pp; a.off = pad_mode == 1 ? 0 : pad;
     a.Ncols = Cin; a.ldw = ld_bwd; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_mode = 0; a.act = ACT_NONE;
-    launch_gemm<true>(a, 4, workspace, (hipStream_t)stream);
+    // stride 2: parity classes (each input-gradient pixel only visits the taps that reach it).  A 1x1 kernel reaches one class
+    // only -- the other three quarters of dxp are zeros, written by a memset node on the same stream.
+    a.cls = (stride == 2) ? 1 : 0;
+    if (a.cls && (KH < 2 || KW < 2) && !accumulate)
+        (void)hipMemsetAsync(dxp, 0, (size_t)B * a.Hd * a.Wd * Cin * sizeof(float), (hipStream_t)stream);
+    // accumulate: dxp += result -- the epilogue's residual input reads the element it is about to overwrite (same thread)
+    if (accumulate) a.res = dxp;
+    launch_gemm<true>(a, 4, a.cls ? nullptr : workspace, (hipStream_t)stream);
     E2E_LAUNCH_CHECK("e2e_conv2d_bwd_data");
     return E2E_OK;
+}
+
+int e2e_conv2d_bwd_data(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout,
+                        int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, float* workspace, void* stream) {
+    return bwd_data_impl(dz, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, 0, workspace, stream);
+}
+
+int e2e_conv2d_bwd_data_acc(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout,
+                            int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, int accumulate, float* workspace,
+                            void* stream) {
+    return bwd_data_impl(dz, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate, workspace, stream);
 }
 
 int e2e_conv2d_gather_adjoint(const float* dxp, int B, int Hs, int Ws, int Cin, int C1, int up, int padded, float* d_src0,
@@ -1087,8 +1145,16 @@ int e2e_conv2d_gather_adjoint(const float* dxp, int B, int Hs, int Ws, int Cin, 
 
 int e2e_conv2d_act_bwd(const float* dy, const float* y, const float* scale, float* dz, int64_t n, int C, int act, void* stream) {
     E2E_REQUIRE(dy && y && dz && n > 0 && C > 0 && act >= 0 && act <= 3, E2E_ERR_ARG, "e2e_conv2d_act_bwd: bad argument");
-    hipLaunchKernelGGL(k_act_bwd, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, scale, dz, n, C, act);
+    hipLaunchKernelGGL(k_act_bwd, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, scale, dz, n, C, act, 0);
     E2E_LAUNCH_CHECK("e2e_conv2d_act_bwd");
+    return E2E_OK;
+}
+
+int e2e_conv2d_act_bwd_acc(const float* dy, const float* y, const float* scale, float* dz, int64_t n, int C, int act, int accumulate,
+                           void* stream) {
+    E2E_REQUIRE(dy && y && dz && n > 0 && C > 0 && act >= 0 && act <= 3, E2E_ERR_ARG, "e2e_conv2d_act_bwd_acc: bad argument");
+    hipLaunchKernelGGL(k_act_bwd, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, scale, dz, n, C, act, accumulate);
+    E2E_LAUNCH_CHECK("e2e_conv2d_act_bwd_acc");
     return E2E_OK;
 }
 
@@ -1114,18 +1180,26 @@ int e2e_head_bwd(const float* dz, const float* x, const float* w, float* dx, flo
     return E2E_OK;
 }
 
-int64_t e2e_conv2d_wgrad_workspace_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int has_bias) {
+// backward-weight decomposition shared by the workspace query and the launch: tile shape, padded GEMM size, pixel slices
+struct WgradPlan { int tm, tn, Mpad, Npad; int64_t S; };
+static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int has_bias) {
+    WgradPlan p;
     const int Ng = KH * KW * Cin + (has_bias ? 1 : 0);
-    const int tm = Cout <= 32 ? 32 : 64, tn = Cout <= 32 ? 128 : 64;         // 32x128 tiles for the thin layers
-    const int Mpad = (Cout + tm - 1) / tm * tm, Npad = (Ng + tn - 1) / tn * tn;
+    p.tm = Cout <= 32 ? 32 : 64; p.tn = Cout <= 32 ? 128 : 64;        // 32x128 tiles for the thin layers
+    p.Mpad = (Cout + p.tm - 1) / p.tm * p.tm; p.Npad = (Ng + p.tn - 1) / p.tn * p.tn;
     const int64_t P = (int64_t)B * Ho * Wo;
-    const int64_t tiles = (int64_t)(Mpad / tm) * (Npad / tn);
+    const int64_t tiles = (int64_t)(p.Mpad / p.tm) * (p.Npad / p.tn);
     int64_t S = (1024 + tiles - 1) / tiles;                 // ~4 workgroups per CU in total
     const int64_t maxS = (P + 255) / 256;                   // at least 256 pixels per slice
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
-    const int64_t folded = (S > WG_FOLD) ? (S + WG_FOLD - 1) / WG_FOLD : 0;
-    return (S + folded) * Mpad * Npad;
+    p.S = S;
+    return p;
+}
+
+int64_t e2e_conv2d_wgrad_workspace_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int has_bias) {
+    const WgradPlan p = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW, has_bias);
+    return p.S * (int64_t)p.Mpad * p.Npad;
 }
 
 int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1, int C1, int up, float* dw, float* dbias,
@@ -1139,21 +1213,12 @@ int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1,
     a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cin = Cin; a.C1 = C1; a.up = up; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_mode = pad_mode; a.has_bias = dbias ? 1 : 0;
     a.Ngemm = KH * KW * Cin + a.has_bias;
-    const int tm = Cout <= 32 ? 32 : 64, tn = Cout <= 32 ? 128 : 64;
-    a.Mpad = (Cout + tm - 1) / tm * tm; a.Npad = (a.Ngemm + tn - 1) / tn * tn;
+    const WgradPlan wp = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW, a.has_bias);
+    const int tm = wp.tm, tn = wp.tn;
+    a.Mpad = wp.Mpad; a.Npad = wp.Npad;
     a.in_sub = in_sub; a.in_mul = in_mul; a.vec = vec;
     const int64_t P = (int64_t)B * Ho * Wo;
-    int64_t S = e2e_conv2d_wgrad_workspace_floats(B, Ho, Wo, Cin, Cout, KH, KW, a.has_bias) / ((int64_t)a.Mpad * a.Npad);
-    if (S > WG_FOLD) S = (S * WG_FOLD + WG_FOLD) / (WG_FOLD + 1) > 0 ? S - (S + WG_FOLD) / (WG_FOLD + 1) : S;   // strip the fold area
-    {   // recompute S exactly as the workspace function does (the division above only bounds it)
-        const int tm0 = Cout <= 32 ? 32 : 64, tn0 = Cout <= 32 ? 128 : 64;
-        const int64_t tiles0 = (int64_t)(a.Mpad / tm0) * (a.Npad / tn0);
-        const int64_t P0 = (int64_t)B * Ho * Wo;
-        S = (1024 + tiles0 - 1) / tiles0;
-        const int64_t maxS = (P0 + 255) / 256;
-        if (S > maxS) S = maxS;
-        if (S < 1) S = 1;
-    }
+    const int64_t S = wp.S;
     // lean VEC-4 kernel: 32 pixels per chunk; needs Cout % 4 == 0, 32-bit offsets and image rows of at least 8 pixels
     const bool lean = vec == 4 && Cout % 4 == 0 && Wo >= 8 && (int64_t)B * Hs * Ws * Cin * 4 < (1ll << 31) && P * Cout * 4 < (1ll << 31);
     const int cbp = lean ? 32 : CBK;
@@ -1171,17 +1236,7 @@ int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1,
         if (vec == 4) hipLaunchKernelGGL((k_wgrad_gemm<2, 2, 4>), g, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_wgrad_gemm<2, 2, 1>), g, dim3(256), 0, st, a);
     }
-    const float* red_in = workspace;
-    int red_S = Sz;
-    if (Sz > WG_FOLD) {
-        float* folded = workspace + S * (int64_t)a.Mpad * a.Npad;
-        const int64_t elems = (int64_t)a.Mpad * a.Npad;
-        const int groups = (Sz + WG_FOLD - 1) / WG_FOLD;
-        hipLaunchKernelGGL(k_slab_fold, dim3(egrid(elems * groups)), dim3(256), 0, st, workspace, Sz, elems, folded);
-        red_in = folded;
-        red_S = groups;
-    }
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(egrid((int64_t)Cout * a.Ngemm)), dim3(256), 0, st, red_in, red_S, a.Mpad, a.Npad, Cout, Cin, KH,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(egrid((int64_t)Cout * a.Ngemm * 4)), dim3(256), 0, st, workspace, Sz, a.Mpad, a.Npad, Cout, Cin, KH,
                        KW, a.has_bias, dw, dbias, accumulate);
     E2E_LAUNCH_CHECK("e2e_conv2d_bwd_weight");
     return E2E_OK;

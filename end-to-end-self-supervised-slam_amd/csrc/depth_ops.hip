@@ -252,11 +252,23 @@ __global__ void k_metrics_final(const float* __restrict__ partials, int nparts, 
 // `participants` (device scalar or NULL): the gradient bucket holds the SUM over the data-parallel ranks and this is how
 // many of them contributed (it travels as an extra element of the same all-reduce); g / max(participants, 1) is the mean
 // -- the division rides in this kernel instead of a separate pass over the 57 MB bucket.  NULL or 1: g unchanged.
+// `schedule` (device, or NULL): the per-step scalars {lr / (1 - beta1^t), sqrt(1 - beta2^t)} for t = 1, 2, ... as the HOST
+// computes them (python doubles rounded to fp32, like torch.optim.Adam), indexed by the device-resident step counter: a
+// launch that is replayed from a captured hipGraph still advances through the bias corrections (k_adam_advance bumps the
+// counter behind it).
 __global__ __launch_bounds__(DT) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                              int64_t n, float one_minus_b1, float b2, float one_minus_b2, float step_size,
-                                             float bc2_sqrt, float eps, const float* __restrict__ participants) {
+                                             float bc2_sqrt, float eps, const float* __restrict__ participants,
+                                             const float2* __restrict__ schedule, const int* __restrict__ step_counter, int schedule_len) {
     const int64_t n4 = n >> 2;
     const float cnt = participants ? fmaxf(participants[0], 1.f) : 1.f;
+    if (schedule) {
+        int t = step_counter[0];
+        t = t < 1 ? 1 : (t > schedule_len ? schedule_len : t);
+        const float2 sc = schedule[t - 1];
+        step_size = sc.x;
+        bc2_sqrt = sc.y;
+    }
     float4* p4 = (float4*)p; const float4* g4 = (const float4*)g; float4* m4 = (float4*)m; float4* v4 = (float4*)v;
     for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * DT) {
         float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
@@ -279,6 +291,8 @@ __global__ __launch_bounds__(DT) void k_adam(float* __restrict__ p, const float*
         p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
     }
 }
+
+__global__ void k_adam_advance(int* __restrict__ step_counter) { step_counter[0] += 1; }
 
 // ---------------------------------------------------------------------------------------------
 static inline int sgrid(int64_t n, int cap = 1024) {
@@ -374,7 +388,8 @@ int e2e_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     hipLaunchKernelGGL(k_adam, dim3(sgrid(n >> 2 > 0 ? n >> 2 : 1, 2048)), dim3(DT), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, n, 1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2_sqrt, eps, (const float*)nullptr);
+                       exp_avg_sq, n, 1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2_sqrt, eps, (const float*)nullptr,
+                       (const float2*)nullptr, (const int*)nullptr, 0);
     E2E_LAUNCH_CHECK("e2e_adam_step");
     return E2E_OK;
 }
@@ -387,8 +402,23 @@ int e2e_adam_step_mean(float* params, const float* grad_sums, const float* parti
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     hipLaunchKernelGGL(k_adam, dim3(sgrid(n >> 2 > 0 ? n >> 2 : 1, 2048)), dim3(DT), 0, (hipStream_t)stream, params, grad_sums, exp_avg,
-                       exp_avg_sq, n, 1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2_sqrt, eps, participants);
+                       exp_avg_sq, n, 1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2_sqrt, eps, participants,
+                       (const float2*)nullptr, (const int*)nullptr, 0);
     E2E_LAUNCH_CHECK("e2e_adam_step_mean");
+    return E2E_OK;
+}
+
+int e2e_adam_step_resident(float* params, const float* grad_sums, const float* participants, float* exp_avg, float* exp_avg_sq, int64_t n,
+                           float beta1, float beta2, float eps, const float* schedule, int schedule_len, int* step_counter, void* stream) {
+    E2E_REQUIRE(n > 0 && params && grad_sums && exp_avg && exp_avg_sq && schedule && schedule_len > 0 && step_counter, E2E_ERR_ARG,
+                "e2e_adam_step_resident: bad argument");
+    E2E_REQUIRE(((uintptr_t)params | (uintptr_t)grad_sums | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0 && (uintptr_t)schedule % 8 == 0,
+                E2E_ERR_ARG, "e2e_adam_step_resident: buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_adam, dim3(sgrid(n >> 2 > 0 ? n >> 2 : 1, 2048)), dim3(DT), 0, st, params, grad_sums, exp_avg, exp_avg_sq, n,
+                       1.0f - beta1, beta2, 1.0f - beta2, 0.f, 1.f, eps, participants, (const float2*)schedule, (const int*)step_counter, schedule_len);
+    hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, st, step_counter);
+    E2E_LAUNCH_CHECK("e2e_adam_step_resident");
     return E2E_OK;
 }
 

@@ -22,65 +22,112 @@ static inline int mgrid(int64_t n, int cap = 4096) {
 // ---------------------------------------------------------------------------------------------------------------------
 // max-pool 3x3 / 2 / pad 1.  torch scans the window row-major and keeps the FIRST maximum (`val > maxval || isnan(val)`),
 // so ties -- frequent behind a ReLU -- send the gradient to the first maximal element; the backward below re-derives
-// exactly that choice.
+// exactly that choice.  NHWC with C % 4 == 0 (the stem has 64 channels).
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int window_argmax(const float* __restrict__ xb, int H, int W, int C, int oh, int ow, int c, float& best) {
-    int arg = -1;
-    best = -INFINITY;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int y = 2 * oh - 1 + kh;
-        if (y < 0 || y >= H) continue;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int x = 2 * ow - 1 + kw;
-            if (x < 0 || x >= W) continue;
-            const float v = xb[((int64_t)y * W + x) * C + c];
-            if (arg < 0) arg = y * W + x;                      // ATen starts at the window's first valid element
-            if (v > best || v != v) { best = v; arg = y * W + x; }
-        }
-    }
-    return arg;
-}
-
+// forward: one thread = one output pixel x 4 channels (float4 loads along the NHWC channel axis)
 __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {
-    const int64_t total = (int64_t)B * Ho * Wo * C;
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         int64_t t = i;
-        const int c = (int)(t % C); t /= C;
+        const int c4 = (int)(t % C4); t /= C4;
         const int ow = (int)(t % Wo); t /= Wo;
         const int oh = (int)(t % Ho); t /= Ho;
         const int b = (int)t;
-        float best;
-        window_argmax(x + (int64_t)b * H * W * C, H, W, C, oh, ow, c, best);
-        y[i] = best;
+        f4v best = (f4v){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int yy = 2 * oh - 1 + kh;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int xx = 2 * ow - 1 + kw;
+                if (xx < 0 || xx >= W) continue;
+                const f4v v = *(const f4v*)(x + (((int64_t)b * H + yy) * W + xx) * C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > best[e] || v[e] != v[e]) best[e] = v[e];
+            }
+        }
+        *(f4v*)(y + i * 4) = best;
     }
 }
 
-// dx[b,y,x,c] = sum over the windows (oh,ow) that contain (y,x) and whose first maximum sits at (y,x) of dy[b,oh,ow,c];
-// accumulate != 0 adds to dx instead of overwriting it (the stem output also feeds the decoder's last skip connection)
+// backward: one thread = one 2x2 block of INPUT pixels x 4 channels.  The block (by, bx) = pixels (2by..2by+1, 2bx..2bx+1) is
+// touched by exactly the four windows (by..by+1, bx..bx+1), which together cover the 5x5 patch of rows 2by-1..2by+3: the
+// patch is loaded once (25 float4), each window's FIRST maximum is re-derived in ATen's scan order, and every pixel of the
+// block gathers the gradients of the windows whose maximum it is (no index tensor, no atomics, fixed order of the <= 4
+// addends).  mul_relu: the result is multiplied by [x > 0] (gradient through the stem's ReLU, taken from its output);
+// accumulate: added to dx.
 __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int B,
-                                                     int H, int W, int C, int Ho, int Wo, int accumulate) {
-    const int64_t total = (int64_t)B * H * W * C;
+                                                     int H, int W, int C, int Ho, int Wo, int accumulate, int mul_relu) {
+    const int C4 = C >> 2, Hb = (H + 1) >> 1, Wb = (W + 1) >> 1;
+    const int64_t total = (int64_t)B * Hb * Wb * C4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         int64_t t = i;
-        const int c = (int)(t % C); t /= C;
-        const int xx = (int)(t % W); t /= W;
-        const int yy = (int)(t % H); t /= H;
+        const int c4 = (int)(t % C4); t /= C4;
+        const int bx = (int)(t % Wb); t /= Wb;
+        const int by = (int)(t % Hb); t /= Hb;
         const int b = (int)t;
-        const float* xb = x + (int64_t)b * H * W * C;
-        float g = 0.f;
-        // windows containing yy: 2*oh - 1 <= yy <= 2*oh + 1
-        const int oh0 = yy >> 1, oh1 = (yy + 1) >> 1, ow0 = xx >> 1, ow1 = (xx + 1) >> 1;
-        for (int oh = oh0; oh <= oh1; ++oh) {
-            if (oh >= Ho) continue;
-            for (int ow = ow0; ow <= ow1; ++ow) {
-                if (ow >= Wo) continue;
-                float best;
-                if (window_argmax(xb, H, W, C, oh, ow, c, best) == yy * W + xx) g += dy[(((int64_t)b * Ho + oh) * Wo + ow) * C + c];
+        const float* xb = x + (int64_t)b * H * W * C + c4 * 4;
+        f4v p[5][5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const int yy = 2 * by - 1 + r, xx = 2 * bx - 1 + c;
+                p[r][c] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? *(const f4v*)(xb + ((int64_t)yy * W + xx) * C)
+                                                                    : (f4v){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             }
-        }
-        dx[i] = accumulate ? dx[i] + g : g;
+        f4v g[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) g[r][c] = (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int wa = 0; wa < 2; ++wa)
+#pragma unroll
+            for (int wb = 0; wb < 2; ++wb) {
+                const int oh = by + wa, ow = bx + wb;
+                if (oh >= Ho || ow >= Wo) continue;
+                const f4v gy = *(const f4v*)(dy + (((int64_t)b * Ho + oh) * Wo + ow) * C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // first maximum of window rows 2wa..2wa+2, cols 2wb..2wb+2 of the patch; out-of-image cells hold -inf and
+                    // are skipped exactly like ATen skips them (the scan starts at the first valid cell)
+                    float best = -INFINITY;
+                    int arg = -1;
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int yy = 2 * by - 1 + 2 * wa + kh, xx = 2 * bx - 1 + 2 * wb + kw;
+                            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                            const float v = p[2 * wa + kh][2 * wb + kw][e];
+                            if (arg < 0) arg = (2 * wa + kh) * 5 + 2 * wb + kw;
+                            if (v > best || v != v) { best = v; arg = (2 * wa + kh) * 5 + 2 * wb + kw; }
+                        }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            if (arg == (1 + r) * 5 + 1 + c) g[r][c][e] += gy[e];
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int yy = 2 * by + r, xx = 2 * bx + c;
+                if (yy >= H || xx >= W) continue;
+                f4v v = g[r][c];
+                if (mul_relu)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = p[1 + r][1 + c][e] > 0.f ? v[e] : 0.f;
+                f4v* d = (f4v*)(dx + (((int64_t)b * H + yy) * W + xx) * C + c4 * 4);
+                if (accumulate) { const f4v o = *d; v = o + v; }
+                *d = v;
+            }
     }
 }
 
@@ -190,18 +237,19 @@ __global__ __launch_bounds__(256) void k_upsample2_concat(const float* __restric
 extern "C" {
 
 int e2e_maxpool3x3s2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
-    E2E_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0, E2E_ERR_ARG, "e2e_maxpool3x3s2_fwd: bad argument");
+    E2E_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, E2E_ERR_ARG, "e2e_maxpool3x3s2_fwd: bad argument (C %% 4 == 0)");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(k_maxpool_fwd, dim3(mgrid((int64_t)B * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C, Ho, Wo);
+    hipLaunchKernelGGL(k_maxpool_fwd, dim3(mgrid((int64_t)B * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C, Ho, Wo);
     E2E_LAUNCH_CHECK("e2e_maxpool3x3s2_fwd");
     return E2E_OK;
 }
 
-int e2e_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int accumulate, void* stream) {
-    E2E_REQUIRE(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0, E2E_ERR_ARG, "e2e_maxpool3x3s2_bwd: bad argument");
+int e2e_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int accumulate, int mul_relu,
+                         void* stream) {
+    E2E_REQUIRE(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, E2E_ERR_ARG, "e2e_maxpool3x3s2_bwd: bad argument (C %% 4 == 0)");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(k_maxpool_bwd, dim3(mgrid((int64_t)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, B, H, W, C, Ho, Wo,
-                       accumulate);
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3(mgrid((int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4), 8192)), dim3(256), 0, (hipStream_t)stream, x,
+                       dy, dx, B, H, W, C, Ho, Wo, accumulate, mul_relu);
     E2E_LAUNCH_CHECK("e2e_maxpool3x3s2_bwd");
     return E2E_OK;
 }

@@ -73,6 +73,8 @@ SIGNATURES = {
     "e2e_depth_metrics": [c_fp, c_fp, c_i64, c_int, c_fp, c_fp, c_fp],
     "e2e_adam_step": [c_fp, c_fp, c_fp, c_fp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_fp],
     "e2e_adam_step_mean": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_fp],
+    "e2e_adam_step_resident": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f32, c_f32, c_f32, c_fp, c_int, c_fp, c_fp],
+    "e2e_masked_mean_lossgrad": [c_fp, c_fp, c_i64, c_f32, c_fp, c_fp, c_fp, c_fp],
     "e2e_aux_workspace_floats": [],
     "e2e_smoothness_lossgrad": [c_fp, c_fp, Strides, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
     "e2e_geometric_consistency_lossgrad": [c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp],
@@ -86,11 +88,13 @@ SIGNATURES = {
     "e2e_conv2d_splitk_workspace_floats": [c_i64, c_int, c_int],
     "e2e_conv2d_act_bwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp],
     "e2e_conv2d_bwd_data": [c_fp, c_fp, c_int, c_fp] + [c_int] * 12 + [c_fp, c_fp],
+    "e2e_conv2d_bwd_data_acc": [c_fp, c_fp, c_int, c_fp] + [c_int] * 13 + [c_fp, c_fp],
+    "e2e_conv2d_act_bwd_acc": [c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_int, c_fp],
     "e2e_conv2d_gather_adjoint": [c_fp] + [c_int] * 7 + [c_fp, c_fp, c_int, c_int, c_fp],
     "e2e_conv2d_wgrad_workspace_floats": [c_int] * 8,
     "e2e_conv2d_bwd_weight": [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp] + [c_int] * 13 + [c_f32, c_f32, c_fp],
     "e2e_maxpool3x3s2_fwd": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp],
-    "e2e_maxpool3x3s2_bwd": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp],
+    "e2e_maxpool3x3s2_bwd": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp],
     "e2e_bn_fold": [c_fp, c_fp, c_fp, c_fp, c_f32, c_fp, c_fp, c_fp, c_int, c_fp],
     "e2e_affine_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_i64, c_int, c_fp],
     "e2e_affine_bwd_workspace_floats": [c_int],

@@ -230,7 +230,7 @@ class _MaxPool(torch.autograd.Function):
         B, C, H, W = x.shape
         g = _cl(g)
         dx = torch.empty_like(x)
-        L.call("e2e_maxpool3x3s2_bwd", L.ptr(x), L.ptr(g), L.ptr(dx), B, H, W, C, 0, L.stream())
+        L.call("e2e_maxpool3x3s2_bwd", L.ptr(x), L.ptr(g), L.ptr(dx), B, H, W, C, 0, 0, L.stream())
         return dx
 
 

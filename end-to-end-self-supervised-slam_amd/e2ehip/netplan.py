@@ -1,0 +1,325 @@
+"""Static launch plan of the depth network (DispResNet_Indoor: ResNet BasicBlock encoder + indoor decoder) for one fixed
+input shape: every activation, gradient, workspace and weight-layout buffer is allocated ONCE, forward and backward are
+fixed sequences of C-ABI launches (no autograd graph, no allocator traffic, no host synchronisation), so a whole
+refinement step can be captured into a hipGraph and replayed (`online_adaption.SLAM`).  This is the hot-path form of
+depth_estimation/networks.py:44-57 (encoder), :277-292 (decoder) and of `loss.backward()` through them
+(online_adaption.py:539); the nn.Module path (per-layer autograd Functions over the same kernels) stays for ad-hoc use
+and is the cross-check in tests/test_gpu_netplan.py.
+
+Backward conventions
+  * every tensor with several consumers (a BasicBlock's input: first convolution + residual add [+ downsample branch]; the
+    encoder features that also feed decoder skips; the stem output: max-pool + last skip) owns ONE gradient buffer; the
+    first contribution of a backward pass stores, later ones accumulate inside the producing kernel (accumulate flags of
+    e2e_conv2d_bwd_data_acc / e2e_conv2d_act_bwd_acc / e2e_conv2d_gather_adjoint / e2e_maxpool3x3s2_bwd) -- no add kernels;
+  * weight / bias / BatchNorm-affine gradients are written straight into the optimiser's flat gradient bucket (each
+    parameter has exactly one writer per step, so the bucket needs no zero-fill);
+  * the backward-weight GEMM of a layer depends only on its dZ, like the backward-data GEMM next to it: with
+    `overlap=True` it goes to a second stream (fork / join inside the captured graph).
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from .conv import ACT, WEIGHT_EPOCH, _ld
+
+_f32 = torch.float32
+
+
+class Buf:
+    """An NHWC activation (B,h,w,C) with its gradient buffer."""
+    __slots__ = ("t", "g", "written", "B", "h", "w", "C")
+
+    def __init__(self, B, h, w, C, dev, need_grad=True):
+        self.B, self.h, self.w, self.C = B, h, w, C
+        self.t = torch.empty(B, h, w, C, device=dev, dtype=_f32)
+        self.g = torch.empty(B, h, w, C, device=dev, dtype=_f32) if need_grad else None
+        self.written = False
+
+    def nchw(self):
+        return self.t.permute(0, 3, 1, 2)
+
+
+def _sink_of(p):
+    s = getattr(p, "_e2e_grad_sink", None)
+    if s is None:                                    # no flat bucket (plain torch optimiser): a private gradient tensor
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        s = p.grad
+    return s
+
+
+class _Conv:
+    def __init__(self, plan, src0, src1, weight, bias, bn, residual, act, stride, pad, pad_mode, up, in_norm):
+        dev = plan.dev
+        self.src0, self.src1, self.res = src0, src1, residual
+        self.weight, self.bias = weight, bias
+        self.Cout, self.Cin, self.KH, self.KW = weight.shape
+        self.C1 = src0.C
+        if self.C1 + (src1.C if src1 is not None else 0) != self.Cin:
+            raise ValueError("channel mismatch in the launch plan")
+        self.up, self.stride, self.pad, self.pm, self.act = up, stride, pad, 1 if pad_mode == "reflect" else 0, ACT[act]
+        self.isub, self.imul = in_norm if in_norm is not None else (0.0, 1.0)
+        B = src0.B
+        self.Hs, self.Ws = src0.h * up, src0.w * up
+        self.Ho, self.Wo = (self.Hs + 2 * pad - self.KH) // stride + 1, (self.Ws + 2 * pad - self.KW) // stride + 1
+        self.out = Buf(B, self.Ho, self.Wo, self.Cout, dev)
+        self.ldf, self.ldb = _ld(self.Cout), _ld(self.Cin)
+        self.wf = torch.zeros(self.KH * self.KW * self.Cin, self.ldf, device=dev, dtype=_f32)
+        self.need_dx = src0.g is not None
+        self.wb = torch.zeros(self.KH * self.KW * self.Cout, self.ldb, device=dev, dtype=_f32) if self.need_dx else None
+        # epilogue vectors: folded frozen BatchNorm (constants) or the live bias parameter
+        self.scale = self.shift = None
+        if bn is not None:
+            w, b, rm, rv, eps = bn
+            with torch.no_grad():
+                self.scale = (w / torch.sqrt(rv + eps)).contiguous()
+                self.shift = (b - rm * self.scale).contiguous()
+        lib = L.load()
+        n = lib.e2e_conv2d_splitk_workspace_floats(B * self.Ho * self.Wo, self.Cout, self.KH * self.KW * self.Cin)
+        self.ws_f = torch.empty(n, device=dev, dtype=_f32) if n else None
+        self.pp = pad if self.pm == 1 else 0
+        self.direct = self.pp == 0 and up == 1 and src1 is None
+        n_el = self.out.t.numel()
+        self.dZ = torch.empty(n_el, device=dev, dtype=_f32) if (self.act != 0 or self.scale is not None) else None
+        if self.need_dx:
+            n = lib.e2e_conv2d_splitk_workspace_floats(B * (self.Hs + 2 * self.pp) * (self.Ws + 2 * self.pp), self.Cin, self.KH * self.KW * self.Cout)
+            self.ws_b = torch.empty(n, device=dev, dtype=_f32) if n else None
+            self.dxp = None if self.direct else torch.empty(B, self.Hs + 2 * self.pp, self.Ws + 2 * self.pp, self.Cin, device=dev, dtype=_f32)
+        self.ws_w = torch.empty(lib.e2e_conv2d_wgrad_workspace_floats(B, self.Ho, self.Wo, self.Cin, self.Cout, self.KH, self.KW,
+                                                                      1 if bias is not None else 0), device=dev, dtype=_f32)
+
+    def layout_row(self):
+        return [self.weight.data_ptr(), self.wf.data_ptr(), self.wb.data_ptr() if self.wb is not None else 0, self.Cout, self.Cin, self.KH, self.KW,
+                self.ldf, self.ldb, 0]
+
+    def fwd(self, plan, st):
+        s = self
+        L.call("e2e_conv2d_fwd", L.ptr(s.src0.t), L.ptr(s.src1.t) if s.src1 is not None else None, s.C1, s.up, L.ptr(s.wf), s.ldf, L.ptr(s.scale),
+               L.ptr(s.shift if s.bias is None else s.bias), L.ptr(s.res.t) if s.res is not None else None, L.ptr(s.out.t), s.src0.B, s.Hs, s.Ws, s.Cin,
+               s.Cout, s.KH, s.KW, s.stride, s.pad, s.pm, s.act, float(s.isub), float(s.imul), L.ptr(s.ws_f), st)
+
+    def bwd(self, plan, st):
+        s = self
+        B, n = s.src0.B, s.out.t.numel()
+        g = s.out.g
+        if s.res is not None:                       # residual branch: d res (+)= dY * act'(Y)
+            L.call("e2e_conv2d_act_bwd_acc", L.ptr(g), L.ptr(s.out.t), None, L.ptr(s.res.g), n, s.Cout, s.act, 1 if s.res.written else 0, st)
+            s.res.written = True
+        dz = g
+        if s.dZ is not None:                        # dZ = dY * act'(Y) * scale: gradient of the convolution output
+            L.call("e2e_conv2d_act_bwd", L.ptr(g), L.ptr(s.out.t), L.ptr(s.scale), L.ptr(s.dZ), n, s.Cout, s.act, st)
+            dz = s.dZ
+        if s.need_dx:
+            if s.direct:
+                L.call("e2e_conv2d_bwd_data_acc", L.ptr(dz), L.ptr(s.wb), s.ldb, L.ptr(s.src0.g), B, s.Hs, s.Ws, s.Cin, s.Cout, s.Ho, s.Wo, s.KH, s.KW,
+                       s.stride, s.pad, s.pm, 1 if s.src0.written else 0, L.ptr(s.ws_b), st)
+                s.src0.written = True
+            else:
+                L.call("e2e_conv2d_bwd_data", L.ptr(dz), L.ptr(s.wb), s.ldb, L.ptr(s.dxp), B, s.Hs, s.Ws, s.Cin, s.Cout, s.Ho, s.Wo, s.KH, s.KW, s.stride,
+                       s.pad, s.pm, L.ptr(s.ws_b), st)
+                s1 = s.src1
+                L.call("e2e_conv2d_gather_adjoint", L.ptr(s.dxp), B, s.Hs, s.Ws, s.Cin, s.C1, s.up, 1 if s.pp else 0, L.ptr(s.src0.g),
+                       L.ptr(s1.g) if s1 is not None else None, 1 if s.src0.written else 0, 1 if (s1 is not None and s1.written) else 0, st)
+                s.src0.written = True
+                if s1 is not None:
+                    s1.written = True
+        st_w = plan.fork(st)
+        L.call("e2e_conv2d_bwd_weight", L.ptr(dz), L.ptr(s.src0.t), L.ptr(s.src1.t) if s.src1 is not None else None, s.C1, s.up,
+               L.ptr(plan.sink(s.weight)), L.ptr(plan.sink(s.bias)) if s.bias is not None else None, L.ptr(s.ws_w), B, s.Hs, s.Ws, s.Cin, s.Cout, s.Ho,
+               s.Wo, s.KH, s.KW, s.stride, s.pad, s.pm, 0, float(s.isub), float(s.imul), st_w)
+
+
+class _Head:
+    """Conv3x3(reflect) 16 -> 1 + 10 sigmoid + 0.01 (networks.py:271-272,289-290): the VALU head kernels."""
+
+    def __init__(self, plan, src, weight, bias, act):
+        self.src, self.weight, self.bias, self.act = src, weight, bias, ACT[act]
+        self.out = Buf(src.B, src.h, src.w, 1, plan.dev)
+        self.dz = torch.empty_like(self.out.t)
+        self.ws = torch.empty(L.load().e2e_head_workspace_floats(), device=plan.dev, dtype=_f32)
+
+    def fwd(self, plan, st):
+        s = self.src
+        L.call("e2e_head_fwd", L.ptr(s.t), L.ptr(self.weight), L.ptr(self.bias), L.ptr(self.out.t), s.B, s.h, s.w, s.C, self.act, st)
+
+    def bwd(self, plan, st):
+        s, n = self.src, self.out.t.numel()
+        L.call("e2e_conv2d_act_bwd", L.ptr(self.out.g), L.ptr(self.out.t), None, L.ptr(self.dz), n, 1, self.act, st)
+        if s.written:
+            raise RuntimeError("the disparity head's input has a single consumer")
+        L.call("e2e_head_bwd", L.ptr(self.dz), L.ptr(s.t), L.ptr(self.weight), L.ptr(s.g), L.ptr(plan.sink(self.weight)),
+               L.ptr(plan.sink(self.bias)) if self.bias is not None else None, L.ptr(self.ws), s.B, s.h, s.w, s.C, st)
+        s.written = True
+
+
+class _MaxPool:
+    def __init__(self, plan, src):
+        self.src = src
+        self.out = Buf(src.B, (src.h - 1) // 2 + 1, (src.w - 1) // 2 + 1, src.C, plan.dev)
+
+    def fwd(self, plan, st):
+        s = self.src
+        L.call("e2e_maxpool3x3s2_fwd", L.ptr(s.t), L.ptr(self.out.t), s.B, s.h, s.w, s.C, st)
+
+    def bwd(self, plan, st):
+        s = self.src
+        L.call("e2e_maxpool3x3s2_bwd", L.ptr(s.t), L.ptr(self.out.g), L.ptr(s.g), s.B, s.h, s.w, s.C, 1 if s.written else 0, 0, st)
+        s.written = True
+
+
+class _BNAffine:
+    """eval-mode BatchNorm whose gamma / beta still train (`downsample.1`, online_adaption.py:182-184)."""
+
+    def __init__(self, plan, src, bn_mod):
+        self.src, self.bn = src, bn_mod
+        C = src.C
+        self.out = Buf(src.B, src.h, src.w, C, plan.dev)
+        self.scale, self.shift, self.rstd = (torch.empty(C, device=plan.dev, dtype=_f32) for _ in range(3))
+        self.ws = torch.empty(L.load().e2e_affine_bwd_workspace_floats(C), device=plan.dev, dtype=_f32)
+
+    def fwd(self, plan, st):
+        b, s = self.bn, self.src
+        L.call("e2e_bn_fold", L.ptr(b.weight), L.ptr(b.bias), L.ptr(b.running_mean), L.ptr(b.running_var), float(b.eps), L.ptr(self.scale),
+               L.ptr(self.shift), L.ptr(self.rstd), s.C, st)
+        L.call("e2e_affine_fwd", L.ptr(s.t), L.ptr(self.scale), L.ptr(self.shift), None, 0, L.ptr(self.out.t), s.t.numel(), s.C, st)
+
+    def bwd(self, plan, st):
+        b, s = self.bn, self.src
+        n = s.t.numel()
+        L.call("e2e_affine_bwd", L.ptr(self.out.g), L.ptr(s.t), L.ptr(b.running_mean), L.ptr(self.rstd), n // s.C, s.C, L.ptr(plan.sink(b.weight)),
+               L.ptr(plan.sink(b.bias)), 0, L.ptr(self.ws), st)
+        L.call("e2e_conv2d_act_bwd_acc", L.ptr(self.out.g), L.ptr(self.out.g), L.ptr(self.scale), L.ptr(s.g), n, s.C, 0, 1 if s.written else 0, st)
+        s.written = True
+
+
+class NetPlan:
+    def __init__(self, model, B, H, W, device, overlap=True):
+        """model: depth_estimation.networks.DispResNet_Indoor in refinement mode (every module eval(); BatchNorms either
+        frozen or -- the downsample ones -- with a trainable affine).  Input: (B,H,W,3) NHWC frames in [0,1]."""
+        from depth_estimation.networks import BasicBlock
+        self.model, self.dev, self.overlap = model, torch.device(device), overlap
+        self.B, self.H, self.W = B, H, W
+        self.ops, self._sinks, self._side = [], {}, None
+        enc, dec = model.encoder.encoder, model.decoder
+        if any(m.training for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)):
+            raise NotImplementedError("the launch plan runs BatchNorm in eval mode (refinement mode, online_adaption.py:175-184)")
+        self.x = Buf(B, H, W, 3, self.dev, need_grad=False)
+
+        def bn_args(bn):
+            return (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+        def conv_bn(src, conv, bn, relu, residual=None, in_norm=None):
+            if bn.weight.requires_grad or bn.bias.requires_grad:
+                if relu or residual is not None or in_norm is not None:
+                    raise NotImplementedError("launch plan: a trainable BatchNorm is expected on the downsample branches only (set_refinement_mode)")
+                z = self._add(_Conv(self, src, None, conv.weight, None, None, None, None, conv.stride[0], conv.padding[0], "zeros", 1, None))
+                return self._add(_BNAffine(self, z, bn))
+            return self._add(_Conv(self, src, None, conv.weight, None, bn_args(bn), residual, "relu" if relu else None, conv.stride[0],
+                                   conv.padding[0], "zeros", 1, in_norm))
+
+        f = conv_bn(self.x, enc.conv1, enc.bn1, True, in_norm=(0.45, 1.0 / 0.225))
+        feats = [f]
+        x = self._add(_MaxPool(self, f))
+        for stage in (enc.layer1, enc.layer2, enc.layer3, enc.layer4):
+            for blk in stage:
+                if not isinstance(blk, BasicBlock):
+                    raise NotImplementedError("launch plan: BasicBlock encoders (ResNet-18 / 34)")
+                idt = x if blk.downsample is None else conv_bn(x, blk.downsample[0], blk.downsample[1], False)
+                h = conv_bn(x, blk.conv1, blk.bn1, True)
+                x = conv_bn(h, blk.conv2, blk.bn2, True, residual=idt)
+            feats.append(x)
+        self.features = feats
+        x = feats[-1]
+        for i in range(4, -1, -1):
+            c0, c1 = dec.convs[("upconv", i, 0)].conv, dec.convs[("upconv", i, 1)].conv
+            x = self._add(_Conv(self, x, None, c0.conv.weight, c0.conv.bias, None, None, "elu", 1, 1, c0.pad_mode, 1, None))
+            skip = feats[i - 1] if (dec.use_skips and i > 0) else None
+            x = self._add(_Conv(self, x, skip, c1.conv.weight, c1.conv.bias, None, None, "elu", 1, 1, c1.pad_mode, 2, None))
+        hc = dec.convs[("dispconv", 0)]
+        if tuple(hc.conv.weight.shape) != (1, 16, 3, 3) or hc.pad_mode != "reflect":
+            raise NotImplementedError("launch plan: the indoor decoder's 16 -> 1 reflect head")
+        self.head = _Head(self, x, hc.conv.weight, hc.conv.bias, "disp")
+        self.ops.append(self.head)
+        self.disp = self.head.out                     # (B,H,W,1) NHWC == (B,1,H,W) contiguous
+        self._desc = None
+        self._desc_key = None
+
+    def _add(self, op):
+        self.ops.append(op)
+        return op.out
+
+    # -- parameters / gradient sinks ---------------------------------------------------------------------------------
+    def parameters(self):
+        out = []
+        for op in self.ops:
+            if isinstance(op, _Conv) or isinstance(op, _Head):
+                out.append(op.weight)
+                if op.bias is not None:
+                    out.append(op.bias)
+            elif isinstance(op, _BNAffine):
+                out += [op.bn.weight, op.bn.bias]
+        return out
+
+    def sink(self, p):
+        """Where the gradient of parameter p is written (its slice of the optimiser's flat bucket when there is one)."""
+        s = self._sinks.get(id(p))
+        if s is None or s.data_ptr() != _sink_of(p).data_ptr():
+            s = self._sinks[id(p)] = _sink_of(p)
+            if not s.is_contiguous() or tuple(s.shape) != tuple(p.shape):
+                raise RuntimeError("gradient sink of a parameter must be a contiguous tensor of the parameter's shape")
+        return s
+
+    # -- weight layouts ------------------------------------------------------------------------------------------------
+    def refresh_layouts(self, st=None):
+        """k-major GEMM copies of every convolution weight in ONE launch (after an optimiser step every one is stale)."""
+        convs = [op for op in self.ops if isinstance(op, _Conv)]
+        key = tuple(op.weight.data_ptr() for op in convs)
+        if self._desc is None or self._desc_key != key:     # the optimiser re-homed the parameters: new descriptor table
+            self._desc = torch.tensor([op.layout_row() for op in convs], dtype=torch.int64).to(self.dev)
+            self._desc_key = key
+        L.call("e2e_conv_weight_layouts_batched", L.ptr(self._desc), len(convs), st if st is not None else L.stream())
+        self._epoch = WEIGHT_EPOCH[0]
+
+    def layouts_current(self):
+        convs = [op for op in self.ops if isinstance(op, _Conv)]
+        return self._desc is not None and self._desc_key == tuple(op.weight.data_ptr() for op in convs) and self._epoch == WEIGHT_EPOCH[0]
+
+    # -- streams -------------------------------------------------------------------------------------------------------
+    def fork(self, st):
+        """Stream for a backward-weight chain: the side stream (after it has seen everything launched so far) or `st`."""
+        if not self.overlap:
+            return st
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.dev)
+        self._side.wait_stream(torch.cuda.current_stream(self.dev))
+        self._forked = True
+        return ctypes.c_void_p(self._side.cuda_stream)
+
+    def join(self):
+        if self.overlap and self._side is not None and getattr(self, "_forked", False):
+            torch.cuda.current_stream(self.dev).wait_stream(self._side)
+            self._forked = False
+
+    # -- the two passes ------------------------------------------------------------------------------------------------
+    def forward(self, frames=None):
+        """frames (B,H,W,3) NHWC in [0,1] (copied into the plan's input buffer; None: the buffer was filled by the caller).
+        Returns the disparity buffer as a (B,1,H,W) view.  Weight layouts must be current (refresh_layouts)."""
+        if frames is not None:
+            self.x.t.copy_(frames)
+        st = L.stream()
+        for op in self.ops:
+            op.fwd(self, st)
+        return self.disp.t.view(self.B, 1, self.H, self.W)
+
+    def backward(self, g_disp=None):
+        """g_disp (B,1,H,W): gradient of the loss wrt the disparity (None: already in self.disp.g).  Parameter gradients
+        go to their sinks; joins the side stream before returning."""
+        if g_disp is not None:
+            self.disp.g.copy_(g_disp.reshape(self.disp.g.shape))
+        st = L.stream()
+        for op in self.ops:
+            op.out.written = False
+        for op in reversed(self.ops):
+            op.bwd(self, st)
+        self.join()

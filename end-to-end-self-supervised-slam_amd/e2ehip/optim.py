@@ -53,12 +53,36 @@ class FusedAdam(torch.optim.Optimizer):
     and frozen parameters (requires_grad False) are skipped -- both are handled by an `active` mask folded
     into the flat layout (inactive parameters are simply left out of the flat buffer)."""
 
+    SCHEDULE_LEN = 1 << 18          # bias-correction table: 262 144 steps x 8 B (a 60-frame sequence takes 177)
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._all = params
         self.flat = None
-        self.steps = 0
+        self.steps = 0              # host-side count of step() CALLS; the step that counts lives on the device (graph replays)
+        self._sched = self._sched_key = self._counter = None
+
+    def _resident_state(self):
+        """Device-resident step counter + the per-step scalars {lr / (1 - beta1^t), sqrt(1 - beta2^t)}, computed on the host in
+        double exactly as torch.optim.Adam does and rounded to fp32 once; rebuilt in place when lr / betas change."""
+        g = self.param_groups[0]
+        key = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]))
+        dev = self.flat.data.device
+        if self._counter is None:
+            self._counter = torch.ones(1, device=dev, dtype=torch.int32)
+            self._sched = torch.empty(self.SCHEDULE_LEN, 2, device=dev, dtype=torch.float32)
+        if self._sched_key != key:
+            t = torch.arange(1, self.SCHEDULE_LEN + 1, dtype=torch.float64)
+            bc1 = 1.0 - torch.pow(torch.tensor(key[1], dtype=torch.float64), t)
+            bc2 = 1.0 - torch.pow(torch.tensor(key[2], dtype=torch.float64), t)
+            self._sched.copy_(torch.stack([key[0] / bc1, torch.sqrt(bc2)], 1).to(torch.float32))
+            self._sched_key = key
+        return self._sched, self._counter
+
+    def steps_done(self):
+        """Optimiser steps taken so far, read from the device counter (host sync)."""
+        return 0 if self._counter is None else int(self._counter.item()) - 1
 
     def _build(self):
         # parameters that take part: trainable AND with a gradient at the first step (torch skips grad None)
@@ -101,6 +125,8 @@ class FusedAdam(torch.optim.Optimizer):
         self.steps += 1
         from . import conv
         conv.WEIGHT_EPOCH[0] += 1                      # the kernel rewrites the weights behind torch's version counters
-        # the bucket holds the SUM over the data-parallel ranks and its tail the number of contributors (1 on a single GPU)
-        L.call("e2e_adam_step_mean", L.ptr(self.flat.data), L.ptr(self.flat.grad), L.ptr(self.flat.participants()), L.ptr(self.m), L.ptr(self.v),
-               self.flat.numel, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self.steps, L.stream())
+        # the bucket holds the SUM over the data-parallel ranks and its tail the number of contributors (1 on a single GPU);
+        # step count and bias corrections are device-resident, so this launch can be captured into a hipGraph and replayed
+        sched, counter = self._resident_state()
+        L.call("e2e_adam_step_resident", L.ptr(self.flat.data), L.ptr(self.flat.grad), L.ptr(self.flat.participants()), L.ptr(self.m), L.ptr(self.v),
+               self.flat.numel, float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), L.ptr(sched), self.SCHEDULE_LEN, L.ptr(counter), L.stream())

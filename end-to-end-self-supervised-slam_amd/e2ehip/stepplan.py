@@ -1,0 +1,173 @@
+"""One refinement step on a keyframe pair as THREE captured hipGraphs over resident buffers (online_adaption.py:274-318 of the
+reference: two depth-net forwards, median scaling, [3-D point loss], warp + photometric + regulariser, backward, Adam):
+
+  graph A   depth network forward on the pair (e2ehip.netplan) + 1/disp + median ratio                 (e2e_depth_scale_fwd)
+  eager     3-D point loss against the global map, forward AND backward wrt the target depth: unproject -> rigid transform ->
+            exact nearest neighbour -> masked mean -> adjoints (7 launches; the map size is a launch argument that changes
+            with every keyframe, so this part is not captured)
+  graph B   fused warp + photometric + regulariser loss-and-gradient (e2e_warp_photo_lossgrad, device geometry), + the 3-D
+            gradient, median-chain backward, depth network backward (weight gradients straight into the flat bucket),
+            [Adam + refresh of the GEMM weight layouts]
+  (N > 1 GPUs: the all-reduce of the bucket runs eagerly between graph B and a third graph with Adam + the refresh)
+
+Replaying a graph costs the host ~15 us; the ~190 launches of a step cost it several milliseconds when issued one by one
+through torch.autograd, which is what bounded round 1's step.  The first call of every graph variant runs eagerly (it IS a
+real step) and is captured right after for the following calls; inside a KernelTimer pass everything runs eagerly so that
+bench.py can time the individual launches.  No host synchronisation anywhere in a step."""
+import torch
+
+from . import _lib as L
+from . import conv as e2e_conv
+from . import dist as edist
+from .fused import LossGradPlan
+from .netplan import NetPlan
+from .ops import fusion_alpha_den
+
+_f32 = torch.float32
+
+
+class RefineStepPlan:
+    def __init__(self, model, optimizer, H, W, device, padding_mode="border", use_mask=True, reg_kind="l2", w_reg=1e-2, w_3d=1.0, sigma=0.6,
+                 overlap=True, use_graphs=True):
+        self.dev, self.H, self.W, self.N = torch.device(device), H, W, H * W
+        self.opt, self.use_graphs, self.w_3d = optimizer, use_graphs, float(w_3d)
+        self.net = NetPlan(model, 2, H, W, self.dev, overlap=overlap)
+        optimizer.prebuild(model.used_parameters())                 # parameters move into the flat bucket; gradient sinks exist from here on
+        if {id(p) for p in self.net.parameters()} != {id(p) for p in model.used_parameters() if p.requires_grad}:
+            raise RuntimeError("launch plan and model disagree about the trainable parameters")
+        f = dict(device=self.dev, dtype=_f32)
+        lib = L.load()
+        # ---- resident tensors of a step (pair order: index 0 = previous keyframe / source, 1 = new keyframe / target) ----
+        self.colors = self.net.x.t                                  # (2,H,W,3) NHWC, the network's input buffer
+        self.gt = torch.zeros(2, H, W, 1, **f)
+        self.K, self.inv_K, self.T, self.pose_tgt = (torch.eye(4, **f).reshape(1, 4, 4).clone() for _ in range(4))
+        self.median_gt = torch.zeros(1, **f)
+        self.ws_med = torch.empty(lib.e2e_median_workspace_bytes(), device=self.dev, dtype=torch.uint8)
+        self.delta, self.depth, self.init = (torch.empty(2, 1, H, W, **f) for _ in range(3))
+        self.md, self.ratio = torch.empty(1, **f), torch.empty(1, **f)
+        self.ws_scale = torch.empty(lib.e2e_depth_scale_workspace_bytes(), device=self.dev, dtype=torch.uint8)
+        self.g_depth = torch.zeros(2, 1, H, W, **f)                 # [d loss / d depth_src, d loss / d depth_tgt]
+        self.reg = reg_kind
+        self.loss = LossGradPlan(1, H, W, self.dev, padding_mode, use_mask, reg_kind, 1.0, float(w_reg) if reg_kind else 0.0)
+        self.loss.g_depth_src, self.loss.g_depth_tgt = self.g_depth[0:1], self.g_depth[1:2]
+        src, tgt = self.colors[0:1].permute(0, 3, 1, 2), self.colors[1:2].permute(0, 3, 1, 2)       # NHWC memory, NCHW views
+        self.loss.bind(self.depth[1:2], self.depth[0:1], self.init[1:2] if reg_kind else None, self.init[0:1] if reg_kind else None,
+                       src, tgt, self.K, self.inv_K, self.T)
+        # ---- 3-D point loss -----------------------------------------------------------------------------------------------
+        self.alpha_den = fusion_alpha_den(sigma)
+        self.V, self.Nm, self.Vg, self.Ng = (torch.empty(1, H, W, 3, **f) for _ in range(4))
+        self.alpha = torch.empty(1, H, W, **f)
+        self.moved, self.g_moved, self.g_cloud = (torch.empty(self.N, 3, **f) for _ in range(3))
+        self.nn_d = torch.empty(self.N, **f)
+        self.nn_idx = torch.empty(self.N, device=self.dev, dtype=torch.int64)
+        self.l3 = torch.zeros(3, **f)                               # {mean nearest-neighbour distance, #valid rows, weight / #valid}
+        self.g_nn = torch.empty(self.N, **f)
+        self.g3 = torch.zeros(1, 1, H, W, **f)
+        self.ws_aux = torch.empty(lib.e2e_aux_workspace_floats(), **f)
+        self._graphs, self._gstream = {}, None
+        self.net.refresh_layouts()
+
+    # ---- per keyframe -----------------------------------------------------------------------------------------------------
+    def set_pair(self, colors_prev, colors_cur, gt_prev, gt_cur, K, T_host, pose_tgt):
+        """Load a keyframe pair into the resident buffers: frames (H,W,3) in [0,1], ground-truth depths (H,W,1), intrinsics K
+        (4,4), relative transform T (4,4) = pinv(P_prev) P_cur and the target pose (4,4).  All copies, no kernels of ours but the
+        median of the ground-truth depths (online_adaption.py:295: torch.median(gt_depths))."""
+        self.colors[0].copy_(colors_prev)
+        self.colors[1].copy_(colors_cur)
+        self.gt[0].copy_(gt_prev)
+        self.gt[1].copy_(gt_cur)
+        self.K[0].copy_(K)
+        self.inv_K[0].copy_(torch.pinverse(K))
+        self.T[0].copy_(T_host, non_blocking=True)
+        self.pose_tgt[0].copy_(pose_tgt)
+        L.call("e2e_median_lower", L.ptr(self.gt), self.gt.numel(), L.ptr(self.median_gt), L.ptr(self.ws_med), L.stream())
+
+    # ---- graph plumbing ---------------------------------------------------------------------------------------------------
+    def _run(self, key, fn):
+        if not self.use_graphs or L.PROFILE_HOOK[0] is not None:
+            return fn()
+        g = self._graphs.get(key)
+        if g is not None:
+            return g.replay()
+        fn()                                                        # first call: a real, eager execution ...
+        cur = torch.cuda.current_stream(self.dev)
+        if self._gstream is None:
+            self._gstream = torch.cuda.Stream(self.dev)
+        self._gstream.wait_stream(cur)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(self._gstream):
+            with torch.cuda.graph(g, stream=self._gstream):         # ... then the same launches recorded (not executed) for the next ones
+                fn()
+        cur.wait_stream(self._gstream)
+        self._graphs[key] = g
+
+    # ---- the pieces -------------------------------------------------------------------------------------------------------
+    def _forward(self):
+        st = L.stream()
+        disp = self.net.forward()
+        L.call("e2e_depth_scale_fwd", L.ptr(disp), L.ptr(self.median_gt), L.ptr(self.delta), L.ptr(self.depth), L.ptr(self.md), L.ptr(self.ratio),
+               L.ptr(self.ws_scale), disp.numel(), st)
+
+    def _loss3d(self, index):
+        """online_adaption.py:457-471 + :638-645: the target frame's cloud in world coordinates (its pose), transformed AGAIN by T
+        (reference quirk), pulled to its nearest neighbours in the detached global map."""
+        st, N = L.stream(), self.N
+        d = self.depth[1:2]
+        L.call("e2e_vertex_normal_maps", L.ptr(d), L.ptr(self.K), L.ptr(self.pose_tgt), float(self.alpha_den), L.ptr(self.V), L.ptr(self.Nm), L.ptr(self.Vg),
+               L.ptr(self.Ng), L.ptr(self.alpha), 1, self.H, self.W, st)
+        L.call("e2e_transform_points", L.ptr(self.Vg), L.ptr(self.T), L.ptr(self.moved), N, 0, st)
+        L.call("e2e_knn1_index_query", L.ptr(self.moved), N, index.n2, index.max_queries, L.ptr(index.ws), L.ptr(self.nn_d), L.ptr(self.nn_idx), st)
+        L.call("e2e_masked_mean_lossgrad", L.ptr(self.nn_d), L.ptr(d), N, self.w_3d, L.ptr(self.l3), L.ptr(self.g_nn), L.ptr(self.ws_aux), st)
+        L.call("e2e_knn1_bwd", L.ptr(self.g_nn), L.ptr(self.moved), L.ptr(index.ref), L.ptr(self.nn_idx), N, L.ptr(self.g_moved), st)
+        L.call("e2e_transform_points", L.ptr(self.g_moved), L.ptr(self.T), L.ptr(self.g_cloud), N, 1, st)
+        L.call("e2e_vertex_maps_bwd", L.ptr(d), L.ptr(self.K), L.ptr(self.pose_tgt), None, L.ptr(self.g_cloud), L.ptr(self.g3), 1, self.H, self.W, st)
+
+    def _backward(self, use_3d, with_adam):
+        st = L.stream()
+        self.loss.step()                                            # losses -> self.loss.loss[0..1]; d/d depth -> self.g_depth
+        if use_3d:                                                  # g_depth_tgt += d(w_3d * l3)/d depth_tgt
+            L.call("e2e_conv2d_act_bwd_acc", L.ptr(self.g3), L.ptr(self.g3), None, L.ptr(self.g_depth[1:2]), self.N, 1, 0, 1, st)
+        L.call("e2e_depth_scale_bwd", L.ptr(self.g_depth), L.ptr(self.delta), L.ptr(self.median_gt), L.ptr(self.md), L.ptr(self.net.disp.g),
+               L.ptr(self.ws_scale), self.g_depth.numel(), st)
+        self.net.backward()
+        if with_adam:
+            self._adam()
+
+    def _adam(self):
+        self.opt.step()
+        self.net.refresh_layouts()
+
+    # ---- public -----------------------------------------------------------------------------------------------------------
+    def step(self, first_step, knn_index=None):
+        """One refinement step on the loaded pair.  first_step: stash 1/disp BEFORE scaling as the regulariser's reference
+        (online_adaption.py:284-285).  knn_index: e2ehip.ops.KnnIndex over the global map, or None on the first keyframe."""
+        use_3d = knn_index is not None
+        self._run("fwd", self._forward)
+        if first_step and self.reg:
+            self.init.copy_(self.delta)
+        if use_3d:
+            self._loss3d(knn_index)
+        multi = edist.world() > 1
+        self._run(("bwd", use_3d, not multi), lambda: self._backward(use_3d, not multi))
+        if multi:
+            edist.exchange_gradients_(self.opt.flat, True)
+            self._run("adam", self._adam)
+        e2e_conv.WEIGHT_EPOCH[0] += 1                               # parameters changed behind torch's version counters (module-path caches)
+        self.net._epoch = e2e_conv.WEIGHT_EPOCH[0]
+
+    def idle_step(self):
+        """A step of a rank without a keyframe in this round (data-parallel runs): zero bucket in, averaged update out."""
+        edist.exchange_gradients_(self.opt.flat, False)
+        self._run("adam", self._adam)
+        e2e_conv.WEIGHT_EPOCH[0] += 1
+        self.net._epoch = e2e_conv.WEIGHT_EPOCH[0]
+
+    def predict_depths(self):
+        """Median-scaled depths of the loaded pair with the current network (the map update's forward pass,
+        online_adaption.py:329-344) -> (2,1,H,W) resident buffer."""
+        self._run("fwd", self._forward)
+        return self.depth
+
+    def losses(self):
+        """(photometric mean, regulariser sum of means, 3-D loss mean) of the last step as device tensors (no sync)."""
+        return self.loss.loss[0], self.loss.loss[1], self.l3[0]

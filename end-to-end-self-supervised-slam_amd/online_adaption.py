@@ -3,12 +3,16 @@ pairs + PointFusion mapping, same class / method names and the same order of ope
 MI355X way:
 
   * the keyframe pair goes through the depth network as ONE batch of two (BN is in eval mode);
-  * 1/disp, the median ratio and its autograd chain are the e2e_depth_scale_* kernels;
+  * 1/disp, the median ratio and its backward chain are the e2e_depth_scale_* kernels;
   * warp + mask + SSIM/L1 + depth regulariser, forward AND backward, are ONE launch (e2e_warp_photo_lossgrad)
     whose d(loss)/d(depth) is injected into the network's backward -- synth / valid / loss map never reach HBM;
   * the 3-D loss is unproject -> rigid transform -> exact nearest neighbour (HIP kernels) on the resident map;
   * Adam is one fused launch over one flat parameter bucket, which is also the single RCCL all-reduce bucket when
     several GPUs refine several sequences (one sequence per rank);
+  * a whole refinement step is a static launch plan over resident buffers, replayed from captured hipGraphs
+    (e2ehip.stepplan / e2ehip.netplan): no autograd graph, no allocator traffic, no host synchronisation in a step;
+    `refinement_autograd` keeps the torch.autograd form of the same step (same kernels) for the off-by-default loss
+    terms and as the cross-check of the plan;
   * the global map is a resident e2ehip.FusionMap updated in place.
 
 reference: online_adaption.py:39-57 (SLAM.__init__), :98-155 (model_init), :175-205, :207-257 (main),
@@ -32,6 +36,7 @@ from e2ehip import dist as edist  # noqa: E402
 from e2ehip import ops  # noqa: E402
 from e2ehip.fused import LossGradPlan  # noqa: E402
 from e2ehip.fusionmap import FusionMap  # noqa: E402
+from e2ehip.stepplan import RefineStepPlan  # noqa: E402
 from e2ehip.synthetic import make_sequence  # noqa: E402
 from utils.training_utils import define_optim, define_schedular, torch_poses_to_transforms  # noqa: E402
 from utils.yaml_configs import load_yaml  # noqa: E402
@@ -54,6 +59,8 @@ class SLAM:
         self.refinement_steps_done = 0
         # backward-weight chains on a second stream next to backward-data (bench.py's per-kernel timing pass switches it off)
         self.overlap_wgrad = os.environ.get("E2E_WGRAD_OVERLAP", "1") == "1"
+        self.use_graphs = os.environ.get("E2E_STEP_GRAPHS", "1") == "1"
+        self.step_plan = None
 
     # ------------------------------------------------------------------------------------------------
     def dataset_init(self):
@@ -146,7 +153,9 @@ class SLAM:
         # one sequence per rank: every rank joins the same number of gradient exchanges; a rank whose
         # sequence has fewer keyframes idles through the surplus rounds as a non-participant
         rounds = edist.common_rounds(len(schedule), self.device)
-        if edist.world() > 1:
+        if self._plan_eligible():
+            self._step_plan()
+        elif edist.world() > 1:
             self.optimizer.prebuild(self.models["depth"].used_parameters())
         for i in range(rounds):
             if i < len(schedule):
@@ -164,6 +173,9 @@ class SLAM:
         """A keyframe round of another rank: contribute a zero bucket to each of its gradient exchanges and apply the
         same averaged update, so that the shared depth network stays identical on every rank."""
         for _ in range(self.args.OPTIMIZATION.refinement_steps):
+            if self.step_plan is not None:
+                self.step_plan.idle_step()
+                continue
             self.optimizer.zero_grad()
             self._exchange_gradients(participating=False)
             self.optimizer.step()
@@ -182,9 +194,65 @@ class SLAM:
         self.first_iter = True
         self.estimated_poses = []
 
+    def _plan_eligible(self):
+        """The launch plan covers the reference's recommended loss set (README.md:146-158: photometric [+ mask] + depth regulariser
+        + 3-D loss); the off-by-default terms go through refinement_autograd."""
+        lo = self.args.LOSS
+        return not any(getattr(lo, f, False) for f in ("geometric", "smoothness", "supervise_depth", "auto_masking", "min_reprojection"))
+
+    def _step_plan(self):
+        if self.step_plan is None:
+            a = self.args
+            use_reg = a.LOSS.depth_regularizer and a.OPTIMIZATION.refinement == "PFT"
+            self.step_plan = RefineStepPlan(self.models["depth"], self.optimizer, self.H, self.W, self.device, a.MODEL.padding_mode,
+                                            a.LOSS.photometric_mask, a.LOSS.depth_regularizer_type if use_reg else None,
+                                            a.LOSS.depth_regularizer_weight if use_reg else 0.0, a.LOSS.three3d_loss_weight, self.map.sigma,
+                                            overlap=self.overlap_wgrad, use_graphs=self.use_graphs)
+            self._inv_K = torch.pinverse(self.intrinsics[0, 0])
+            self._poses_h = self.poses.detach().cpu()
+        self.step_plan.net.overlap = self.overlap_wgrad
+        return self.step_plan
+
     def refinement(self, prev, cur, max_steps=None):
         """One keyframe: `OPTIMIZATION.refinement_steps` optimisation steps on the pair (prev, cur), then the map update
         (online_adaption.py:259-327).  max_steps (bench.py) truncates the optimisation loop to time an exact step count."""
+        if not self._plan_eligible():
+            return self.refinement_autograd(prev, cur, max_steps)
+        a = self.args
+        sp = self._step_plan()
+        # T = pinv(P_prev) P_cur (training_utils.py:191-216) on the host: poses are dataset inputs, 4x4 algebra
+        T = torch_poses_to_transforms(self._poses_h[:, [prev, cur]])[0, 1]
+        sp.set_pair(self.colors[0, prev], self.colors[0, cur], self.gt_depths[0, prev], self.gt_depths[0, cur], self.intrinsics[0, 0], T, self.poses[0, cur])
+        sp.inv_K[0].copy_(self._inv_K)
+        use_3d = a.LOSS.three3d_loss and not self.first_iter
+        index = self.map.knn_index(self.H * self.W) if use_3d else None     # one grid build per keyframe, three queries
+        nsteps = a.OPTIMIZATION.refinement_steps if max_steps is None else min(int(max_steps), a.OPTIMIZATION.refinement_steps)
+        for refine_step in range(nsteps):
+            sp.step(refine_step == 0, index)
+            self.refinement_steps_done += 1
+            if a.DEBUG.print_metrics:
+                lp, lr, l3 = sp.losses()
+                m = ops.depth_metrics(sp.gt[1], sp.depth[1], a.DATA.name == "TUM")
+                total = lp + (a.LOSS.depth_regularizer_weight * lr if sp.reg else 0.0)
+                l3v = l3 if use_3d else torch.zeros((), device=self.device)
+                if use_3d:
+                    total = total + a.LOSS.three3d_loss_weight * l3
+                rec = torch.cat([total.reshape(1), lp.reshape(1), lr.reshape(1), sp.ratio.reshape(1), m, l3v.reshape(1)]).cpu()
+                self._log_step(rec, refine_step, nsteps)
+        # map update (online_adaption.py:329-366): one more forward with the refined network, then PointFusion
+        depth = sp.predict_depths()
+        self._update_map(self.colors[0, prev], self.colors[0, cur], depth, self.poses[0, prev], self.poses[0, cur])
+
+    def _log_step(self, rec, refine_step, nsteps):
+        self.log.append(rec)
+        print("Refine_Step:", refine_step, "Total_Loss:", round(rec[0].item(), 5), "abs_rel: ", round(rec[4].item(), 5),
+              "rmse: ", round(rec[6].item(), 5), "a1: ", round(rec[8].item(), 5))
+        if refine_step == nsteps - 1:
+            self.mean_abs.append(rec[4].item())
+
+    def refinement_autograd(self, prev, cur, max_steps=None):
+        """The same keyframe through torch.autograd over the per-layer Functions (same kernels, one launch at a time): the form
+        that carries the off-by-default loss terms, and the cross-check of the launch plan (tests/test_gpu_driver.py)."""
         a = self.args
         colors, gt, poses = self._pair(prev, cur)
         transform = torch_poses_to_transforms(poses)
@@ -227,11 +295,7 @@ class SLAM:
                 if l3 is not None:
                     total = total + a.LOSS.three3d_loss_weight * l3.detach()
                 rec = torch.cat([total.reshape(1), loss2, ratio.reshape(1), m, (l3.detach() if l3 is not None else torch.zeros((), device=self.device)).reshape(1)]).cpu()
-                self.log.append(rec)
-                print("Refine_Step:", refine_step, "Total_Loss:", round(rec[0].item(), 5), "abs_rel: ", round(rec[4].item(), 5),
-                      "rmse: ", round(rec[6].item(), 5), "a1: ", round(rec[8].item(), 5))
-                if refine_step == nsteps - 1:
-                    self.mean_abs.append(rec[4].item())
+                self._log_step(rec, refine_step, nsteps)
         self.create_refined_pointcloud(colors, gt, poses, median_gt)
 
     def compute_3d_loss(self, d_tgt, K, pose_tgt, T):
@@ -253,20 +317,26 @@ class SLAM:
 
     @torch.no_grad()
     def create_refined_pointcloud(self, colors, gt, poses, median_gt):
+        """online_adaption.py:329-366 (autograd form: one more network forward, median scaling, then the map update)."""
         disp = self.models["depth"](colors[0], 0)[("disp", 0, 0)]
         depth, _, _ = ops.depth_from_disp_median_scaled(disp, median_gt)
+        return self._update_map(colors[0, 0], colors[0, 1], depth, poses[0, 0], poses[0, 1])
+
+    @torch.no_grad()
+    def _update_map(self, rgb_prev, rgb_cur, depth, pose_prev, pose_cur):
+        """PointFusion map step(s) with the refined, median-scaled depths (2,1,H,W) of the pair (online_adaption.py:347-363)."""
         K = self.intrinsics[0, 0]
         if self.first_iter:
-            self.map.step(colors[0, 0], depth[0, 0], K, poses[0, 0])
-        live_pose = poses[0, 1]
+            self.map.step(rgb_prev, depth[0, 0], K, pose_prev)
+        live_pose = pose_cur
         if self.args.MODEL.odom != "gt":
             # the reference passes prev_frame here (online_adaption.py:362-363): frame-to-model odometry from the
             # previous keyframe's pose; the map is fused with the ESTIMATED pose and the pose itself is dropped there --
             # we keep it to report the trajectory error
             from e2ehip import icp
-            live_pose, _ = icp.frame_to_model(self.map, depth[1, 0], K, poses[0, 0], numiters=self.args.MODEL.numiters, mode=self.args.MODEL.odom)
-            self.estimated_poses.append((live_pose, poses[0, 1]))
-        self.map.step(colors[0, 1], depth[1, 0], K, live_pose)
+            live_pose, _ = icp.frame_to_model(self.map, depth[1, 0], K, pose_prev, numiters=self.args.MODEL.numiters, mode=self.args.MODEL.odom)
+            self.estimated_poses.append((live_pose, pose_cur))
+        self.map.step(rgb_cur, depth[1, 0], K, live_pose)
         return self.map
 
     def absolute_trajectory_error(self):

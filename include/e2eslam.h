@@ -302,6 +302,13 @@ int e2e_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
 int e2e_adam_step_mean(float* params, const float* grad_sums, const float* participants, float* exp_avg,
                        float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                        int step, void* stream);
+/* The hipGraph-safe form: the step count lives on the device.  schedule (device, 8-byte aligned) holds for t = 1..len the
+ * pair { lr / (1 - beta1^t), sqrt(1 - beta2^t) } exactly as the host computes it for e2e_adam_step (doubles rounded to
+ * fp32); the launch uses entry step_counter[0] (1-based, clamped to len) and a second one-thread kernel advances the
+ * counter, so a captured step replays through the bias corrections.  participants may be NULL (= 1). */
+int e2e_adam_step_resident(float* params, const float* grad_sums, const float* participants, float* exp_avg,
+                           float* exp_avg_sq, int64_t n, float beta1, float beta2, float eps,
+                           const float* schedule, int schedule_len, int* step_counter, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Depth network convolutions -- depth_estimation/networks.py:44-57,157-189,277-292             */
@@ -341,11 +348,20 @@ int64_t e2e_conv2d_splitk_workspace_floats(int64_t rows, int cols, int K);
 /* dZ = dY * act'(Y) * scale[c]  (Y = the op's OUTPUT; scale may be NULL). */
 int e2e_conv2d_act_bwd(const float* dy, const float* y, const float* scale, float* dz, int64_t n,
                        int C, int act, void* stream);
+/* the same with dz += ... when accumulate != 0 (a tensor with several consumers, e.g. a BasicBlock's input that feeds
+ * both the first convolution and the residual add: networks.py -> torchvision BasicBlock.forward). */
+int e2e_conv2d_act_bwd_acc(const float* dy, const float* y, const float* scale, float* dz, int64_t n,
+                           int C, int act, int accumulate, void* stream);
 
 /* gradient wrt the virtual (padded when pad_mode == 1) input: dxp (B,Hs+2p,Ws+2p,Cin). */
 int e2e_conv2d_bwd_data(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs,
                         int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride,
                         int pad, int pad_mode, float* workspace, void* stream);
+/* the same with dxp += ... when accumulate != 0 (pad_mode 0 only: the padded domain of a reflection-padded layer is folded
+ * by e2e_conv2d_gather_adjoint, which has its own accumulate flags). */
+int e2e_conv2d_bwd_data_acc(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs,
+                            int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride,
+                            int pad, int pad_mode, int accumulate, float* workspace, void* stream);
 /* adjoint of the gather: dxp -> d_src0 (B,Hs/up,Ws/up,C1) [, d_src1 (B,Hs,Ws,Cin-C1)]; every output
  * element sums its reflect-pad copies and its up x up readers in a fixed order (no atomics). */
 int e2e_conv2d_gather_adjoint(const float* dxp, int B, int Hs, int Ws, int Cin, int C1, int up,
@@ -363,10 +379,11 @@ int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1,
 
 /* ResNet stem max-pool, nn.MaxPool2d(3, 2, 1) (networks.py:53 -> torchvision resnet.maxpool): x (B,H,W,C) NHWC ->
  * y (B,(H-1)/2+1,(W-1)/2+1,C).  The backward keeps no index tensor: every input element re-derives the first maximum
- * (ATen's scan order) of the <= 4 windows that contain it; accumulate != 0 adds to dx. */
+ * (ATen's scan order) of the <= 4 windows that contain it; accumulate != 0 adds to dx, mul_relu != 0 multiplies the
+ * result by [x > 0] (the stem's ReLU, whose output x is).  C % 4 == 0. */
 int e2e_maxpool3x3s2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
 int e2e_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C,
-                         int accumulate, void* stream);
+                         int accumulate, int mul_relu, void* stream);
 
 /* eval-mode BatchNorm with a TRAINABLE affine (the reference freezes parameters whose name contains "bn",
  * online_adaption.py:182-184, so encoder.layerN.0.downsample.1 keeps training): scale = gamma / sqrt(var + eps),
@@ -444,6 +461,13 @@ int e2e_masked_l1_lossgrad(const float* prediction, const float* sparse_gt, cons
  * gradient goes to the first minimal channel. */
 int e2e_min_reprojection_lossgrad(const float* errors, int B, int C, int H, int W, float* loss_out,
                                   float* g_errors, float* workspace, void* stream);
+
+/* mean of values[i] over the elements whose gate[i] != 0, and weight x its gradient: the 3-D point loss
+ * (online_adaption.py:638-645; loss/losses.py:57-63 `torch.mean(dists)`) over the valid-depth pixels without the
+ * reference's boolean indexing (dynamic shape + host sync): gate = the depth map.  out3 = {mean, count, weight / count};
+ * g_values (may be NULL) = weight * [gate != 0] / count.  workspace: e2e_aux_workspace_floats() floats. */
+int e2e_masked_mean_lossgrad(const float* values, const float* gate, int64_t n, float weight, float* out3,
+                             float* g_values, float* workspace, void* stream);
 
 /* train_depth.py:224-237 process_disparity: disp_pair (2,1,H,W) = net(img), net(flip(img)) ->
  * out (1,1,H,W); bwd: g_out (H,W) -> g_disp_pair (2,1,H,W). */

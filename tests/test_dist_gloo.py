@@ -40,7 +40,7 @@ def _worker(rank, world, port, q):
     from online_adaption import SLAM
     steps = []
     fake_opt = types.SimpleNamespace(flat=flat, zero_grad=flat.zero_grad, step=lambda: steps.append(float(flat.participants())), _build=lambda: None)
-    fake = types.SimpleNamespace(optimizer=fake_opt, args=types.SimpleNamespace(OPTIMIZATION=types.SimpleNamespace(refinement_steps=3)))
+    fake = types.SimpleNamespace(optimizer=fake_opt, step_plan=None, args=types.SimpleNamespace(OPTIMIZATION=types.SimpleNamespace(refinement_steps=3)))
     fake._exchange_gradients = types.MethodType(SLAM._exchange_gradients, fake)
     if rank == 0:                                    # rank 0 refines a keyframe (3 steps), rank 1 idles through the same round
         for _ in range(3):
@@ -72,7 +72,7 @@ def test_two_rank_gloo_exchange():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=90) for _ in procs]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

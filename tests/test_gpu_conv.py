@@ -48,6 +48,10 @@ CASES = [
     (1, 32, 0, 1, 20, 36, 16, 3, 1, 1, "reflect", "elu", False, True, False),     # Cout = 16 (half MFMA tile)
     (1, 16, 0, 2, 24, 40, 16, 3, 1, 1, "reflect", "elu", False, True, False),     # upconv(0,1): upsample without skip
     (1, 128, 0, 1, 30, 40, 128, 3, 1, 1, "zeros", None, False, False, False),     # medium tile config
+    (2, 64, 0, 1, 30, 44, 128, 3, 2, 1, "zeros", "relu", True, False, False),     # stride 2, several tiles per parity class (backward-data classes)
+    (1, 128, 0, 1, 17, 23, 256, 3, 2, 1, "zeros", "relu", True, False, False),    # stride 2, odd height and width (unequal classes)
+    (2, 64, 0, 1, 16, 24, 128, 1, 2, 0, "zeros", None, False, False, False),      # 1x1 / 2 downsample: three of the four classes are zeros
+    (1, 16, 0, 1, 18, 26, 32, 3, 2, 1, "zeros", None, False, False, False),       # stride 2 with Cin = 16 (thin 128x32 tiles, chunk depth 16)
 ]
 
 
