@@ -31,7 +31,8 @@ for p in (ROOT, os.path.join(ROOT, "end-to-end-self-supervised-slam_amd"), os.pa
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA, dense (= the fp32 vector peak)
-CONV_ENTRY_POINTS = ("e2e_conv2d_fwd", "e2e_conv2d_bwd_data", "e2e_conv2d_bwd_data_acc", "e2e_conv2d_bwd_weight")
+CONV_ENTRY_POINTS = ("e2e_conv2d_fwd", "e2e_conv2d_bwd_data", "e2e_conv2d_bwd_data_acc", "e2e_conv2d_bwd_data_fused", "e2e_conv2d_bwd_weight",
+                     "e2e_conv2d_bwd_weight_scaled")
 WARP_ENTRY_POINTS = ("e2e_warp_photo_lossgrad_hostgeo", "e2e_warp_photo_lossgrad", "e2e_warp_photo_lossgrad_chain")
 
 

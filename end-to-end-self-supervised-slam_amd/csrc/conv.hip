@@ -53,6 +53,12 @@ struct ConvArgs {
     // 3x3 kernel.  cls != 0: workgroup blockIdx.x handles tile blockIdx.x >> 2 of class blockIdx.x & 3 with that tap subset
     // (the plain transposed gather walks all 9 taps for every pixel and finds 3/4 of them to be stride holes).
     int cls;
+    // backward-data only: the gradient this launch produces belongs to the tensor x_in = act_in(u) that the forward convolution READ
+    // (same [row][Ncols] layout as the output); with dact != 0 the epilogue multiplies by act_in'(u), taken from x_in itself
+    // (ReLU: [x > 0]; ELU: x > 0 ? 1 : x + 1), so the launch emits d loss / d u -- the gradient with respect to the PRE-activation
+    // of the producing layer -- and that layer needs no separate activation-backward pass (e2ehip.netplan).
+    const float* xin;
+    int dact;
     int64_t bytes0, bytes1, bytesw;   // extents of src0 / src1 / w for the buffer resources (< 2 GB each)
 };
 
@@ -61,6 +67,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
     if (act == ACT_DISP) return 10.f / (1.f + expf(-v)) + 0.01f;          // networks.py:290
     return v;
+}
+
+// act'(u) recovered from the activation's OUTPUT y = act(u)
+__device__ __forceinline__ float act_deriv(float y, int act) {
+    if (act == ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
+    return 1.f;
 }
 
 // source pixel for output-domain pixel (yd,xd) and tap (kh,kw); returns false when the tap reads a structural zero
@@ -294,26 +307,102 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         __syncthreads();
     }
 
-    if (a.ksplit > 1) {                                      // raw partial sums; the epilogue runs after the reduction
-        float* slab = a.slab + (int64_t)blockIdx.z * Ntot * a.Ncols;
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------
+    // A lane holds column (lane & 31) and rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of each 32x32 block: the 16 rows sit at FIXED
+    // distances from the lane's first row, so every store / residual load is one buffer instruction with the lane's byte offset in
+    // the VGPR and the row distance in the (wave-uniform) scalar offset -- no per-element address arithmetic; rows past the end of
+    // the tensor get an out-of-range VGPR offset (one compare + select per element in the last row tile; the hardware's range
+    // check does not include the scalar offset) and are dropped by the hardware.  The activation is selected once, outside the
+    // element loops.  (The first version spent ~145 instructions per element here -- 64-bit row
+    // arithmetic, bounds tests and a branch tree per element -- and every wave of a launch runs its epilogue at the same time, so
+    // none of it overlapped with MFMA work: ~30 % of the kernel's cycles on the 64x64 layers.)
+    const int64_t out_elems = (int64_t)a.B * a.Hd * a.Wd * a.Ncols;
+    if (a.ksplit > 1) {                                      // raw partial sums; the scale / shift / activation run after the reduction
+        const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.slab + (int64_t)blockIdx.z * Ntot * a.Ncols), 0,
+                                                                             (int)(Ntot * a.Ncols * 4), 0x00020000);
 #pragma unroll
         for (int u = 0; u < TM; ++u)
 #pragma unroll
             for (int t = 0; t < TN; ++t) {
                 const int col = c0 + (wn * TN + t) * 32 + (lane & 31);
-                if (col >= a.Ncols) continue;
+                const int64_t nb = n0 + (wm * TM + u) * 32 + 4 * khalf;
+                const unsigned voff = (col < a.Ncols && nb < Ntot) ? (unsigned)((nb * a.Ncols + col) * 4) : OOB;
+                const int left = (int)((Ntot - nb < 32) ? Ntot - nb : 32);      // rows of this block that exist (the range check
+                float v[16];                                                    // ignores the scalar offset: mask them in the VGPR)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int64_t n = n0 + (wm * TM + u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    if (n < Ntot) slab[n * a.Ncols + col] = acc[u][t][r];
-                }
+                    v[r] = acc[u][t][r];
+                    asm volatile("" : "+v"(v[r]));          // hipcc (ROCm 7.2) otherwise stores accumulator register 0 sixteen times
+                }                                           // when the store data comes straight out of the AGPR tuple
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rsl, ((r & 3) + 8 * (r >> 2) < left) ? voff : OOB,
+                                                          ((r & 3) + 8 * (r >> 2)) * a.Ncols * 4, 0);
             }
         return;
     }
-    // ---- epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5) ----------------------------
-    // class form: GEMM row n = (b, yc, xc) of the class lattice -> output pixel (b, 2 yc + py, 2 xc + px); the two divisions per
-    // row are multiplications by ceil(2^32 / d) (exact for n * d < 2^32: n < 2^21 rows, d < 2^10)
-    const unsigned hw_c = (unsigned)(Hc * Wc), mg_hw = CLS ? (0xFFFFFFFFu / hw_c) + 1u : 0u, mg_w = CLS ? (0xFFFFFFFFu / (unsigned)Wc) + 1u : 0u;
+    if (!CLS) {
+        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(out_elems * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, (int)(a.res ? out_elems * 4 : 0), 0x00020000);
+        const bool has_res = a.res != nullptr;
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)((TRANSPOSED && a.xin) ? a.xin : a.out), 0,
+                                                                             (int)((TRANSPOSED && a.xin) ? out_elems * 4 : 0), 0x00020000);
+#pragma unroll
+        for (int u = 0; u < TM; ++u)
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const int col = c0 + (wn * TN + t) * 32 + (lane & 31);
+                const bool col_ok = col < a.Ncols;
+                const float sc = (a.scale && col_ok) ? a.scale[col] : 1.f, sh = (a.shift && col_ok) ? a.shift[col] : 0.f;
+                const int64_t nb = n0 + (wm * TM + u) * 32 + 4 * khalf;
+                const unsigned voff0 = (col_ok && nb < Ntot) ? (unsigned)((nb * a.Ncols + col) * 4) : OOB;
+                const int left = (int)((Ntot - nb < 32) ? Ntot - nb : 32);      // rows of this block that exist: the hardware's range check
+                unsigned vo[16];                                                // ignores the scalar offset, so rows past the end are masked here
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vo[r] = ((r & 3) + 8 * (r >> 2) < left) ? voff0 : OOB;
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[u][t][r], sc, sh);
+                if (TRANSPOSED && a.dact) {                     // x (act') of the tensor this gradient belongs to
+                    float xx[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        xx[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, vo[r], ((r & 3) + 8 * (r >> 2)) * a.Ncols * 4, 0));
+                    if (a.dact == ACT_RELU) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = xx[r] > 0.f ? v[r] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = xx[r] > 0.f ? v[r] : v[r] * (xx[r] + 1.f);
+                    }
+                }
+                if (has_res) {
+                    float rr[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        rr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsr, vo[r], ((r & 3) + 8 * (r >> 2)) * a.Ncols * 4, 0));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += rr[r];
+                }
+                if (a.act == ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+                } else if (a.act == ACT_ELU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : expm1f(v[r]);
+                } else if (a.act == ACT_DISP) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = 10.f / (1.f + expf(-v[r])) + 0.01f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rso, vo[r], ((r & 3) + 8 * (r >> 2)) * a.Ncols * 4, 0);
+            }
+        return;
+    }
+    // class form (3 small layers): GEMM row n = (b, yc, xc) of the class lattice -> output pixel (b, 2 yc + py, 2 xc + px); the image
+    // index by comparisons, the row by a multiplication with ceil(2^32 / Wc) (exact: rem * Wc < 2^32)
+    const unsigned hw_c = (unsigned)(Hc * Wc), mg_w = (0xFFFFFFFFu / (unsigned)Wc) + 1u;
 #pragma unroll
     for (int u = 0; u < TM; ++u)
 #pragma unroll
@@ -325,13 +414,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int64_t n = n0 + (wm * TM + u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 if (n >= Ntot) continue;
-                int64_t orow = n;
-                if (CLS) {
-                    const unsigned un = (unsigned)n, b = hw_c == 1u ? un : __umulhi(un, mg_hw), rem = un - b * hw_c;
-                    const unsigned yc = Wc == 1 ? rem : __umulhi(rem, mg_w), xc = rem - yc * (unsigned)Wc;
-                    orow = ((int64_t)b * a.Hd + 2 * yc + py) * a.Wd + 2 * xc + px;
-                }
+                unsigned rem = (unsigned)n, b = 0;
+                while (rem >= hw_c) { rem -= hw_c; ++b; }
+                const unsigned yc = Wc == 1 ? rem : __umulhi(rem, mg_w), xc = rem - yc * (unsigned)Wc;
+                const int64_t orow = ((int64_t)b * a.Hd + 2 * yc + py) * a.Wd + 2 * xc + px;
                 float v = fmaf(acc[u][t][r], sc, sh);
+                if (a.dact) v *= act_deriv(a.xin[orow * a.Ncols + col], a.dact);
                 if (a.res) v += a.res[orow * a.Ncols + col];
                 a.out[orow * a.Ncols + col] = apply_act(v, a.act);
             }
@@ -340,12 +428,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
 
 __global__ __launch_bounds__(256) void k_conv_splitk_epilogue(const float* __restrict__ slab, int S, int64_t total, int Ncols,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
-                                                              const float* __restrict__ res, float* __restrict__ out, int act) {
+                                                              const float* res, float* out, int act, const float* __restrict__ xin, int dact) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         for (int z = 0; z < S; ++z) v += slab[(int64_t)z * total + i];        // fixed order
         const int col = (int)(i % Ncols);
         v = fmaf(v, scale ? scale[col] : 1.f, shift ? shift[col] : 0.f);
+        if (dact) v *= act_deriv(xin[i], dact);
         if (res) v += res[i];
         out[i] = apply_act(v, act);
     }
@@ -665,14 +754,16 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
 }
 
 // sum the S slabs and scatter to dW (Cout,Cin,KH,KW) [accumulating when `accumulate`] and the bias gradient, in ONE launch:
-// a workgroup owns 64 consecutive output elements; its 4 waves sum the slabs z = w, w + 4, w + 8, ... (independent loads,
-// 8 in flight per lane) and the four partial sums are combined through LDS in the fixed order ((p0 + p1) + p2) + p3 --
-// bitwise reproducible.  (Round 1 ran this as k_slab_fold + k_wgrad_reduce: two launches and a second trip of the folded
-// slabs through HBM for every layer.)
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, int S, int Mpad, int Npad, int Cout, int Cin,
-                                                      int KH, int KW, int has_bias, float* __restrict__ dw, float* __restrict__ dbias,
-                                                      int accumulate) {
-    __shared__ float part[4][64];
+// a workgroup owns 64 consecutive output elements and spreads the slabs over ZL slab lanes (lane w sums z = w, w + ZL, ...:
+// at most ~8 independent loads per thread, all in flight together); the ZL partial sums are combined through LDS in the fixed
+// order ((p0 + p1) + p2) + ... -- bitwise reproducible.  scale (may be NULL): per-output-channel factor applied to the sum (the
+// folded BatchNorm scale, when the GEMM ran on dA instead of dZ = dA * scale).  (Round 1 ran this as k_slab_fold + k_wgrad_reduce:
+// two launches and a second trip of the folded slabs through HBM for every layer.)
+template <int ZL>
+__global__ __launch_bounds__(64 * ZL) void k_wgrad_reduce(const float* __restrict__ slabs, int S, int Mpad, int Npad, int Cout, int Cin,
+                                                         int KH, int KW, int has_bias, float* __restrict__ dw, float* __restrict__ dbias,
+                                                         int accumulate, const float* __restrict__ scale) {
+    __shared__ float part[ZL][64];
     const int Kconv = KH * KW * Cin, Ng = Kconv + (has_bias ? 1 : 0);
     const int64_t total = (int64_t)Cout * Ng;
     const int e = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -684,18 +775,21 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
         const float* src = slabs + (int64_t)m * Npad + n;
         float sacc = 0.f;
         int z = w;
-        for (; z + 28 < S; z += 32) {
+        for (; z + 7 * ZL < S; z += 8 * ZL) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = on ? src[(int64_t)(z + 4 * j) * slab_elems] : 0.f;
+            for (int j = 0; j < 8; ++j) v[j] = on ? src[(int64_t)(z + ZL * j) * slab_elems] : 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) sacc += v[j];
         }
-        for (; z < S; z += 4) sacc += on ? src[(int64_t)z * slab_elems] : 0.f;
+        for (; z < S; z += ZL) sacc += on ? src[(int64_t)z * slab_elems] : 0.f;
         part[w][e] = sacc;
         __syncthreads();
         if (w == 0 && on) {
-            const float t = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+            float t = part[0][e];
+#pragma unroll
+            for (int j = 1; j < ZL; ++j) t += part[j][e];
+            if (scale) t *= scale[m];
             if (n < Kconv) {
                 const int tap = n / Cin, ci = n - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
                 float* d = dw + (((int64_t)m * Cin + ci) * KH + kh) * KW + kw;
@@ -728,13 +822,16 @@ __global__ __launch_bounds__(256) void k_weight_layouts(const float* __restrict_
 }
 
 // all layers of a network in ONE launch (after an optimiser step every layout is stale): blockIdx.y = layer, descriptor
-// table of 10 int64 per layer on the device: {w, w_fwd, w_bwd, Cout, Cin, KH, KW, ld_fwd, ld_bwd, reserved}
+// table of 10 int64 per layer on the device: {w, w_fwd, w_bwd, Cout, Cin, KH, KW, ld_fwd, ld_bwd, bwd_scale (float* or 0)}
 __global__ __launch_bounds__(256) void k_weight_layouts_batched(const long long* __restrict__ desc) {
     const long long* d = desc + (int64_t)blockIdx.y * 10;
     const float* __restrict__ w = (const float*)d[0];
     float* __restrict__ wf = (float*)d[1];
     float* __restrict__ wb = (float*)d[2];
     const int Cout = (int)d[3], Cin = (int)d[4], KH = (int)d[5], KW = (int)d[6], ldf = (int)d[7], ldb = (int)d[8];
+    // optional per-output-channel factor folded into the BACKWARD layout only (a folded BatchNorm scale: dX = (dA * scale) W^T is
+    // computed as dA (scale W)^T, so the backward GEMM reads dA directly -- e2ehip.netplan)
+    const float* __restrict__ bsc = (const float*)d[9];
     const int T = KH * KW;
     constexpr int TMAX = 9, TS = 32;
     __shared__ float tile[TMAX][TS][TS + 1];
@@ -746,7 +843,7 @@ __global__ __launch_bounds__(256) void k_weight_layouts_batched(const long long*
             const int ci = (int)(r % Cin), co = (int)(r / Cin);
             const float v = w[i];
             if (wf) wf[((int64_t)tap * Cin + ci) * ldf + co] = v;
-            if (wb) wb[((int64_t)tap * Cout + co) * ldb + ci] = v;
+            if (wb) wb[((int64_t)tap * Cout + co) * ldb + ci] = bsc ? v * bsc[co] : v;
         }
         return;
     }
@@ -773,7 +870,7 @@ __global__ __launch_bounds__(256) void k_weight_layouts_batched(const long long*
             for (int e = threadIdx.x; e < T * nco * nci; e += 256) {
                 const int ci_l = e % nci, r = e / nci;
                 const int co_l = r % nco, tap = r / nco;
-                wb[((int64_t)tap * Cout + co0 + co_l) * ldb + ci0 + ci_l] = tile[tap][co_l][ci_l];
+                wb[((int64_t)tap * Cout + co0 + co_l) * ldb + ci0 + ci_l] = bsc ? tile[tap][co_l][ci_l] * bsc[co0 + co_l] : tile[tap][co_l][ci_l];
             }
         __syncthreads();
     }
@@ -799,7 +896,8 @@ __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ dy, c
 // Every destination element GATHERS its contributors in a fixed order (no atomics): the reflect-pad copies of a pixel
 // and, for src0, the up x up block of full-resolution pixels that read it.
 __global__ __launch_bounds__(256) void k_gather_adjoint(const float* __restrict__ dxp, int B, int Hs, int Ws, int Cin, int C1, int up,
-                                                        int pp, float* __restrict__ d0, float* __restrict__ d1, int acc0, int acc1) {
+                                                        int pp, float* __restrict__ d0, float* __restrict__ d1, int acc0, int acc1,
+                                                        const float* __restrict__ x0, int act0, const float* __restrict__ x1, int act1) {
     const int Hp = Hs + 2 * pp, Wp = Ws + 2 * pp, C2 = Cin - C1, Hl = Hs / up, Wl = Ws / up;
     const int64_t n0 = (int64_t)B * Hl * Wl * C1, n1 = (int64_t)B * Hs * Ws * C2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n0 + n1; i += (int64_t)gridDim.x * 256) {
@@ -829,6 +927,7 @@ __global__ __launch_bounds__(256) void k_gather_adjoint(const float* __restrict_
             }
         float* d = first ? d0 + i : d1 + (i - n0);
         const int acc = first ? acc0 : acc1;
+        if (first ? act0 : act1) s *= act_deriv(first ? x0[i] : x1[i - n0], first ? act0 : act1);     // -> gradient wrt the producer's pre-activation
         *d = acc ? *d + s : s;
     }
 }
@@ -870,7 +969,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ x, c
 
 // d/dx: every input pixel gathers the (reflect-aware) outputs that read it:  dx[p,ci] = sum_{q, tap: src(q,tap)=p} dz[q] w[tap,ci]
 __global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ dx,
-                                                       int B, int H, int W) {
+                                                       int B, int H, int W, const float* __restrict__ xin, int dact) {
     __shared__ float sw[9 * HC];
     for (int i = threadIdx.x; i < 9 * HC; i += 256) {
         const int ci = i / 9, tap = i - ci * 9;
@@ -901,6 +1000,15 @@ __global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__
                         for (int c = 0; c < HC; ++c) acc[c] = fmaf(g, wt[c], acc[c]);
                     }
                 }
+            }
+        }
+        if (dact) {                                              // -> gradient wrt the pre-activation of the layer that produced x
+            const f4v* xi = (const f4v*)(xin + n * HC);
+#pragma unroll
+            for (int q = 0; q < HC / 4; ++q) {
+                const f4v xv = xi[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[q * 4 + e] *= act_deriv(xv[e], dact);
             }
         }
         f4v* o = (f4v*)(dx + n * HC);
@@ -969,82 +1077,111 @@ __global__ __launch_bounds__(256) void k_head_wreduce(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------------------
 static inline int egrid(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
-// split-K factor for a GEMM of Ntot rows x Ncols columns x K: only when the 64x64 tiling leaves most CUs idle
-static int splitk_factor(int64_t Ntot, int Ncols, int K, int vec) {
-    if (vec != 4 || Ncols < 64) return 1;
-    const int64_t tiles = ((Ntot + 63) / 64) * ((Ncols + 63) / 64);
-    if (tiles >= 384) return 1;
-    int64_t S = 768 / tiles;
-    if (S > 8) S = 8;
-    if (S > K / 128) S = K / 128;                          // at least 128 k per slice
-    return S < 2 ? 1 : (int)S;
+// K-chunk depth: 32 when the channel count allows (a chunk never straddles a tap; a row's chunk is one 128-byte line)
+#define GEMM_LAUNCH(WM, WN, TM, TN, GRID)                                                                                   \
+    do {                                                                                                                    \
+        if (cb == 32) hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 4, TR, 32>), GRID, dim3(64 * WM * WN), 0, st, a);     \
+        else hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 4, TR, 16>), GRID, dim3(64 * WM * WN), 0, st, a);              \
+    } while (0)
+
+// A GEMM decomposition: rows x columns of the workgroup tile and the number of K slices (split-K).
+struct GemmCfg { int bm, bn, S; };
+static int g_wgrad_target = 1024;          // workgroups a backward-weight launch aims at (tuning hook: e2e_conv_wgrad_target)
+static GemmCfg g_force = {0, 0, 0};          // tuning hook (tools/gemm_tune.py): e2e_conv_gemm_force(); 0 = automatic choice
+
+// waves of a tile shape (one 32x32xTMxTN accumulator block per wave) -- 0: unsupported shape
+static int tile_waves(int bm, int bn) {
+    if ((bm == 64 && bn == 64) || (bm == 128 && bn == 64) || (bm == 128 && bn == 128) || (bm == 128 && bn == 32) || (bm == 32 && bn == 128)) return 4;
+    if ((bm == 32 && bn == 64) || (bm == 64 && bn == 32)) return 2;
+    if (bm == 32 && bn == 32) return 1;
+    return 0;
 }
 
-// K-chunk depth: 32 when the channel count allows (a chunk never straddles a tap; a row's chunk is one 128-byte line)
-#define GEMM_LAUNCH(WM, WN, TM, TN, GRID)                                                                        \
-    do {                                                                                                         \
-        if (cb == 32) hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 4, TR, 32>), GRID, dim3(256), 0, st, a);   \
-        else hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 4, TR, 16>), GRID, dim3(256), 0, st, a);            \
-    } while (0)
+// The decomposition of a GEMM of rows x cols x K.  Calibrated on tools/gemm_tune.py (profiles/r02_gemm_tune*.txt: every tile
+// family x 1..16 K slices timed on every layer shape of the 480x640 network, forward and backward-data):
+//   * 64x64 tiles (4 waves, one 32x32 block each) are within 3 % of the best family wherever the GEMM has more than 32
+//     columns; thin GEMMs take 128x32 (64x32 when that leaves fewer than ~2 workgroups per CU);
+//   * the number of K slices that is fastest puts ~460 workgroups on the 256 CUs (all of them resident at once, ~1.8 per CU):
+//     S = round(460 / tiles), e.g. layer2 (300 tiles) 57 us unsplit -> 41 us at S = 3, upconv(4,0) (40 tiles) 34 -> 26 us at
+//     S = 12 -- as long as a slice keeps at least 128 of K.  Finer tiles WITHOUT split-K (32x64, 32x32: 1200-2400 workgroups)
+//     do not pay: the kernels are not bound by tile quantisation but by the phases every wave of a launch goes through at
+//     the same time (operand set-up, epilogue), which more but smaller workgroups do not shorten.
+static GemmCfg choose_cfg(int64_t rows, int cols, int K, int cb, bool allow_split) {
+    if (g_force.bm) { GemmCfg f = g_force; if (!allow_split) f.S = 1; if (f.bm == 128 && f.bn == 128 && cb != 16) f.bn = 64; return f; }
+    GemmCfg c = {64, 64, 1};
+    if (cols <= 32) {
+        c.bm = 128; c.bn = 32;
+        if (((rows + 127) / 128) * ((cols + 31) / 32) < 600) c.bm = 64;
+    }
+    if (allow_split && cols > 32) {
+        const int64_t tiles = ((rows + c.bm - 1) / c.bm) * ((cols + c.bn - 1) / c.bn);
+        const int nchunks = (K + cb - 1) / cb;
+        int S = (int)((460 + tiles / 2) / tiles);
+        if (S > 16) S = 16;
+        while (S > 1 && (nchunks / S) * cb < 128) --S;
+        c.S = S < 1 ? 1 : S;
+    }
+    return c;
+}
+
+template <bool TR>
+static void launch_tile(ConvArgs& a, int cb, GemmCfg c, dim3 g, hipStream_t st) {
+    if (c.bm == 64 && c.bn == 64) GEMM_LAUNCH(2, 2, 1, 1, g);
+    else if (c.bm == 128 && c.bn == 64) GEMM_LAUNCH(2, 2, 2, 1, g);
+    else if (c.bm == 128 && c.bn == 128) hipLaunchKernelGGL((k_conv_gemm<2, 2, 2, 2, 4, TR, 16>), g, dim3(256), 0, st, a);
+    else if (c.bm == 128 && c.bn == 32) GEMM_LAUNCH(4, 1, 1, 1, g);
+    else if (c.bm == 32 && c.bn == 128) GEMM_LAUNCH(1, 4, 1, 1, g);
+    else if (c.bm == 32 && c.bn == 64) GEMM_LAUNCH(1, 2, 1, 1, g);
+    else if (c.bm == 64 && c.bn == 32) GEMM_LAUNCH(2, 1, 1, 1, g);
+    else GEMM_LAUNCH(1, 1, 1, 1, g);
+}
+
+static int64_t splitk_max_floats(int64_t rows, int cols, int K, int vec) {
+    if (vec != 4) return 0;
+    return (int64_t)16 * rows * cols;            // the chooser never takes more than 16 slices
+}
 
 template <bool TR>
 static void launch_gemm(ConvArgs a, int vec, float* workspace, hipStream_t st) {
     const int64_t Ntot = (int64_t)a.B * a.Hd * a.Wd;
     const int K = a.KH * a.KW * a.Cin;
-    const int S = workspace ? splitk_factor(Ntot, a.Ncols, K, vec) : 1;
     const int cb = (vec == 4 && a.Cin % 32 == 0 && (a.C1 == a.Cin || a.C1 % 32 == 0)) ? 32 : 16;
-    a.ksplit = S; a.cps = 0; a.slab = workspace;
+    a.ksplit = 1; a.cps = 0; a.slab = workspace;
     a.bytes0 = (int64_t)a.B * (a.Hs / a.up) * (a.Ws / a.up) * a.C1 * 4;
     a.bytes1 = (int64_t)a.B * a.Hs * a.Ws * (a.Cin - a.C1) * 4;
     a.bytesw = (int64_t)K * a.ldw * 4;
-    if (TR && a.cls) {
-        // 4 parity classes x the tiles of the largest class (ceil(Hd/2) x ceil(Wd/2) pixels per image); blockIdx.x & 3 = class
-        const int64_t Nc = (int64_t)a.B * ((a.Hd + 1) / 2) * ((a.Wd + 1) / 2);
-        a.ksplit = 1;
-        if (a.Ncols <= 32) {
-            dim3 g((unsigned)(4 * ((Nc + 127) / 128)), (unsigned)((a.Ncols + 31) / 32));
-            GEMM_LAUNCH(4, 1, 1, 1, g);
-        } else {
-            dim3 g((unsigned)(4 * ((Nc + 63) / 64)), (unsigned)((a.Ncols + 63) / 64));
-            GEMM_LAUNCH(2, 2, 1, 1, g);
-        }
-        return;
-    }
-    if (S > 1) {
-        const int nchunks = (K + cb - 1) / cb;
-        a.cps = (nchunks + S - 1) / S;
-        const int Sz = (nchunks + a.cps - 1) / a.cps;
-        a.ksplit = Sz;
-        dim3 g((unsigned)((Ntot + 63) / 64), (unsigned)((a.Ncols + 63) / 64), (unsigned)Sz);
-        GEMM_LAUNCH(2, 2, 1, 1, g);
-        const int64_t total = Ntot * a.Ncols;
-        hipLaunchKernelGGL(k_conv_splitk_epilogue, dim3(egrid(total)), dim3(256), 0, st, workspace, Sz, total, a.Ncols, a.scale, a.shift, a.res, a.out, a.act);
-        return;
-    }
     if (vec == 1) {
         dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 63) / 64));
         hipLaunchKernelGGL((k_conv_gemm<4, 1, 1, 2, 1, TR, 16>), g, dim3(256), 0, st, a);
         return;
     }
-    // tile choice (rows x cols): big tiles reuse each operand fragment twice (half the LDS / L2 traffic per MFMA) but need
-    // enough workgroups to fill 256 CUs; thin layers (Cout <= 32) use 128x32.
-    auto wgs = [&](int bm, int bn) { return ((Ntot + bm - 1) / bm) * ((a.Ncols + bn - 1) / bn); };
-    if (a.Ncols <= 32) {
-        dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 31) / 32));
-        GEMM_LAUNCH(4, 1, 1, 1, g);
-    } else if (a.Ncols >= 128 && wgs(128, 128) >= 512) {
-        dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 127) / 128));
-        hipLaunchKernelGGL((k_conv_gemm<2, 2, 2, 2, 4, TR, 16>), g, dim3(256), 0, st, a);      // 128 x 128 (depth 32 would need > 64 KB of LDS)
-    } else if (wgs(128, 64) >= 512) {
-        dim3 g((unsigned)((Ntot + 127) / 128), (unsigned)((a.Ncols + 63) / 64));
-        GEMM_LAUNCH(2, 2, 2, 1, g);                                                            // 128 x 64
-    } else if (wgs(64, 64) >= 256 || a.Ncols < 128) {
-        dim3 g((unsigned)((Ntot + 63) / 64), (unsigned)((a.Ncols + 63) / 64));
-        GEMM_LAUNCH(2, 2, 1, 1, g);                                                            // 64 x 64
-    } else {
-        dim3 g((unsigned)((Ntot + 31) / 32), (unsigned)((a.Ncols + 127) / 128));
-        GEMM_LAUNCH(1, 4, 1, 1, g);                                                            // 32 x 128
+    if (TR && a.cls) {
+        // 4 parity classes x the tiles of the largest class (ceil(Hd/2) x ceil(Wd/2) pixels per image); blockIdx.x & 3 = class.
+        // The classes carry 1, 2, 2 and 4 of the 9 taps: price the decomposition on the average (K * 9/16 of a class of Nc rows x 4)
+        const int64_t Nc = (int64_t)a.B * ((a.Hd + 1) / 2) * ((a.Wd + 1) / 2);
+        GemmCfg c = choose_cfg(Nc * 4, a.Ncols, (K * 9 / 16 + cb - 1) / cb * cb, cb, false);
+        if (c.bm == 128 && c.bn == 128) c.bn = 64;
+        dim3 g((unsigned)(4 * ((Nc + c.bm - 1) / c.bm)), (unsigned)((a.Ncols + c.bn - 1) / c.bn));
+        launch_tile<TR>(a, cb, c, g, st);
+        return;
     }
+    const GemmCfg c = choose_cfg(Ntot, a.Ncols, K, cb, workspace != nullptr);
+    if (c.S > 1) {
+        const int nchunks = (K + cb - 1) / cb;
+        a.cps = (nchunks + c.S - 1) / c.S;
+        const int Sz = (nchunks + a.cps - 1) / a.cps;
+        a.ksplit = Sz;
+        if (Sz > 1) {
+            dim3 g((unsigned)((Ntot + c.bm - 1) / c.bm), (unsigned)((a.Ncols + c.bn - 1) / c.bn), (unsigned)Sz);
+            launch_tile<TR>(a, cb, c, g, st);
+            const int64_t total = Ntot * a.Ncols;
+            hipLaunchKernelGGL(k_conv_splitk_epilogue, dim3(egrid(total)), dim3(256), 0, st, workspace, Sz, total, a.Ncols, a.scale, a.shift, a.res, a.out, a.act, a.xin, a.dact);
+            return;
+        }
+        a.ksplit = 1; a.cps = 0;
+    }
+    dim3 g((unsigned)((Ntot + c.bm - 1) / c.bm), (unsigned)((a.Ncols + c.bn - 1) / c.bn));
+    launch_tile<TR>(a, cb, c, g, st);
 }
 
 extern "C" {
@@ -1069,8 +1206,37 @@ int e2e_conv_weight_layouts_batched(const long long* desc, int nlayers, void* st
 
 /* floats of split-K workspace a GEMM of `rows` x `cols` with reduction length K may use (0: never splits) */
 int64_t e2e_conv2d_splitk_workspace_floats(int64_t rows, int cols, int K) {
-    const int S = splitk_factor(rows, cols, K, (K % 16 == 0) ? 4 : 1);
-    return S > 1 ? (int64_t)S * rows * cols : 0;
+    if (K % 16 != 0) return 0;
+    int smax = 1;                                            // the largest slice count any chunk depth would choose
+    for (int cb = 16; cb <= 32; cb += 16) {
+        const GemmCfg c = choose_cfg(rows, cols, K, cb, true);
+        if (c.S > smax) smax = c.S;
+    }
+    if (g_force.bm && g_force.S > smax) smax = g_force.S;
+    return smax > 1 ? (int64_t)smax * rows * cols : 0;
+}
+
+/* tuning hook: number of workgroups a backward-weight launch spreads its pixel slices over (default 1024) */
+int e2e_conv_wgrad_target(int workgroups) {
+    E2E_REQUIRE(workgroups >= 64 && workgroups <= 8192, E2E_ERR_ARG, "e2e_conv_wgrad_target: 64..8192");
+    g_wgrad_target = workgroups;
+    return E2E_OK;
+}
+
+/* the decomposition the built-in cost model picks for a GEMM of rows x cols x K at chunk depth cb (host-only query) */
+int e2e_conv_gemm_choice(int64_t rows, int cols, int K, int chunk_depth, int allow_split, int* out3) {
+    E2E_REQUIRE(out3 && rows > 0 && cols > 0 && K > 0 && (chunk_depth == 16 || chunk_depth == 32), E2E_ERR_ARG, "e2e_conv_gemm_choice: bad argument");
+    const GemmCfg c = choose_cfg(rows, cols, K, chunk_depth, allow_split != 0);
+    out3[0] = c.bm; out3[1] = c.bn; out3[2] = c.S;
+    return E2E_OK;
+}
+
+/* tuning hook: force the tile shape / slice count of every following GEMM launch (bm = 0: automatic).  Not thread safe;
+ * used by tools/gemm_tune.py only. */
+int e2e_conv_gemm_force(int bm, int bn, int ksplit) {
+    E2E_REQUIRE(bm == 0 || (tile_waves(bm, bn) != 0 && ksplit >= 1 && ksplit <= 16), E2E_ERR_ARG, "e2e_conv_gemm_force: unsupported tile");
+    g_force.bm = bm; g_force.bn = bn; g_force.S = ksplit;
+    return E2E_OK;
 }
 
 int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const float* w_fwd, int ld_fwd, const float* scale,
@@ -1098,7 +1264,10 @@ int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const f
 }
 
 static int bwd_data_impl(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout, int Ho, int Wo,
-                         int KH, int KW, int stride, int pad, int pad_mode, int accumulate, float* workspace, void* stream) {
+                         int KH, int KW, int stride, int pad, int pad_mode, int accumulate, const float* x_in, int in_act, float* workspace,
+                         void* stream) {
+    E2E_REQUIRE(in_act == 0 || (x_in && (in_act == ACT_RELU || in_act == ACT_ELU) && pad_mode == 0), E2E_ERR_ARG,
+                "e2e_conv2d_bwd_data: the fused input-activation derivative takes ReLU / ELU, the activation's output and a zero-padded layer");
     E2E_REQUIRE(dz && w_bwd && dxp && B > 0 && Cin > 0 && Cout > 0 && Cout % 16 == 0, E2E_ERR_ARG, "e2e_conv2d_bwd_data: bad argument (Cout %% 16 == 0)");
     E2E_REQUIRE(ld_bwd % 4 == 0 && ld_bwd >= Cin && (stride == 1 || stride == 2), E2E_ERR_ARG, "e2e_conv2d_bwd_data: bad sizes");
     E2E_REQUIRE((int64_t)B * Ho * Wo * Cout * 4 < (1ll << 31) && (int64_t)KH * KW * Cout * ld_bwd * 4 < (1ll << 31), E2E_ERR_ARG,
@@ -1116,6 +1285,7 @@ static int bwd_data_impl(const float* dz, const float* w_bwd, int ld_bwd, float*
         (void)hipMemsetAsync(dxp, 0, (size_t)B * a.Hd * a.Wd * Cin * sizeof(float), (hipStream_t)stream);
     // accumulate: dxp += result -- the epilogue's residual input reads the element it is about to overwrite (same thread)
     if (accumulate) a.res = dxp;
+    a.xin = in_act ? x_in : nullptr; a.dact = in_act;
     launch_gemm<true>(a, 4, a.cls ? nullptr : workspace, (hipStream_t)stream);
     E2E_LAUNCH_CHECK("e2e_conv2d_bwd_data");
     return E2E_OK;
@@ -1123,13 +1293,19 @@ static int bwd_data_impl(const float* dz, const float* w_bwd, int ld_bwd, float*
 
 int e2e_conv2d_bwd_data(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout,
                         int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, float* workspace, void* stream) {
-    return bwd_data_impl(dz, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, 0, workspace, stream);
+    return bwd_data_impl(dz, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, 0, nullptr, 0, workspace, stream);
 }
 
 int e2e_conv2d_bwd_data_acc(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout,
                             int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, int accumulate, float* workspace,
                             void* stream) {
-    return bwd_data_impl(dz, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate, workspace, stream);
+    return bwd_data_impl(dz, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate, nullptr, 0, workspace, stream);
+}
+
+int e2e_conv2d_bwd_data_fused(const float* da, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout,
+                              int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, int accumulate, const float* x_in,
+                              int in_act, float* workspace, void* stream) {
+    return bwd_data_impl(da, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate, x_in, in_act, workspace, stream);
 }
 
 int e2e_conv2d_gather_adjoint(const float* dxp, int B, int Hs, int Ws, int Cin, int C1, int up, int padded, float* d_src0,
@@ -1138,8 +1314,21 @@ int e2e_conv2d_gather_adjoint(const float* dxp, int B, int Hs, int Ws, int Cin, 
                 "e2e_conv2d_gather_adjoint: bad argument");
     const int64_t n = (int64_t)B * (Hs / up) * (Ws / up) * C1 + (int64_t)B * Hs * Ws * (Cin - C1);
     hipLaunchKernelGGL(k_gather_adjoint, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, dxp, B, Hs, Ws, Cin, C1, up, padded ? 1 : 0,
-                       d_src0, d_src1, accumulate0, accumulate1);
+                       d_src0, d_src1, accumulate0, accumulate1, (const float*)nullptr, 0, (const float*)nullptr, 0);
     E2E_LAUNCH_CHECK("e2e_conv2d_gather_adjoint");
+    return E2E_OK;
+}
+
+int e2e_conv2d_gather_adjoint_act(const float* dxp, int B, int Hs, int Ws, int Cin, int C1, int up, int padded, float* d_src0, float* d_src1,
+                                  int accumulate0, int accumulate1, const float* src0, int act0, const float* src1, int act1, void* stream) {
+    E2E_REQUIRE(dxp && d_src0 && B > 0 && Cin > 0 && C1 > 0 && C1 <= Cin && (C1 == Cin || d_src1) && (up == 1 || up == 2), E2E_ERR_ARG,
+                "e2e_conv2d_gather_adjoint_act: bad argument");
+    E2E_REQUIRE((act0 == 0 || src0) && (act1 == 0 || src1) && act0 >= 0 && act0 <= 2 && act1 >= 0 && act1 <= 2, E2E_ERR_ARG,
+                "e2e_conv2d_gather_adjoint_act: an activation derivative needs the activation's output");
+    const int64_t n = (int64_t)B * (Hs / up) * (Ws / up) * C1 + (int64_t)B * Hs * Ws * (Cin - C1);
+    hipLaunchKernelGGL(k_gather_adjoint, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, dxp, B, Hs, Ws, Cin, C1, up, padded ? 1 : 0,
+                       d_src0, d_src1, accumulate0, accumulate1, src0, act0, src1, act1);
+    E2E_LAUNCH_CHECK("e2e_conv2d_gather_adjoint_act");
     return E2E_OK;
 }
 
@@ -1166,18 +1355,28 @@ int e2e_head_fwd(const float* x, const float* w, const float* bias, float* y, in
     return E2E_OK;
 }
 int64_t e2e_head_workspace_floats(void) { return (int64_t)HEAD_PARTS * (9 * HC + 1); }
-int e2e_head_bwd(const float* dz, const float* x, const float* w, float* dx, float* dw, float* dbias, float* workspace, int B, int H,
-                 int W, int Cin, void* stream) {
-    E2E_REQUIRE(dz && x && w && workspace && B > 0 && H >= 2 && W >= 2 && Cin == HC, E2E_ERR_ARG, "e2e_head_bwd: bad argument");
+static int head_bwd_impl(const float* dz, const float* x, const float* w, float* dx, float* dw, float* dbias, float* workspace, int B, int H,
+                         int W, int Cin, int in_act, void* stream) {
+    E2E_REQUIRE(dz && x && w && workspace && B > 0 && H >= 2 && W >= 2 && Cin == HC && in_act >= 0 && in_act <= 2, E2E_ERR_ARG, "e2e_head_bwd: bad argument");
     E2E_REQUIRE((int64_t)B * H * W * HC < (1ll << 31), E2E_ERR_ARG, "e2e_head_bwd: activation too large for 32-bit element offsets");
     hipStream_t st = (hipStream_t)stream;
-    if (dx) hipLaunchKernelGGL(k_head_bwd_data, dim3(egrid((int64_t)B * H * W)), dim3(256), 0, st, dz, w, dx, B, H, W);
+    if (dx) hipLaunchKernelGGL(k_head_bwd_data, dim3(egrid((int64_t)B * H * W)), dim3(256), 0, st, dz, w, dx, B, H, W, x, in_act);
     if (dw) {
         hipLaunchKernelGGL(k_head_bwd_weight, dim3(HEAD_PARTS), dim3(256), 0, st, dz, x, workspace, B, H, W);
         hipLaunchKernelGGL(k_head_wreduce, dim3(9 * HC + 1), dim3(256), 0, st, workspace, HEAD_PARTS, dw, dbias);
     }
     E2E_LAUNCH_CHECK("e2e_head_bwd");
     return E2E_OK;
+}
+
+int e2e_head_bwd(const float* dz, const float* x, const float* w, float* dx, float* dw, float* dbias, float* workspace, int B, int H,
+                 int W, int Cin, void* stream) {
+    return head_bwd_impl(dz, x, w, dx, dw, dbias, workspace, B, H, W, Cin, 0, stream);
+}
+
+int e2e_head_bwd_act(const float* dz, const float* x, const float* w, float* dx, float* dw, float* dbias, float* workspace, int B, int H,
+                     int W, int Cin, int in_act, void* stream) {
+    return head_bwd_impl(dz, x, w, dx, dw, dbias, workspace, B, H, W, Cin, in_act, stream);
 }
 
 // backward-weight decomposition shared by the workspace query and the launch: tile shape, padded GEMM size, pixel slices
@@ -1189,7 +1388,7 @@ static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, in
     p.Mpad = (Cout + p.tm - 1) / p.tm * p.tm; p.Npad = (Ng + p.tn - 1) / p.tn * p.tn;
     const int64_t P = (int64_t)B * Ho * Wo;
     const int64_t tiles = (int64_t)(p.Mpad / p.tm) * (p.Npad / p.tn);
-    int64_t S = (1024 + tiles - 1) / tiles;                 // ~4 workgroups per CU in total
+    int64_t S = (g_wgrad_target + tiles - 1) / tiles;       // pixel slices: ~g_wgrad_target workgroups in total
     const int64_t maxS = (P + 255) / 256;                   // at least 256 pixels per slice
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
@@ -1202,9 +1401,9 @@ int64_t e2e_conv2d_wgrad_workspace_floats(int B, int Ho, int Wo, int Cin, int Co
     return p.S * (int64_t)p.Mpad * p.Npad;
 }
 
-int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1, int C1, int up, float* dw, float* dbias,
-                          float* workspace, int B, int Hs, int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride,
-                          int pad, int pad_mode, int accumulate, float in_sub, float in_mul, void* stream) {
+static int bwd_weight_impl(const float* dz, const float* src0, const float* src1, int C1, int up, float* dw, float* dbias, float* workspace, int B,
+                           int Hs, int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, int accumulate,
+                           float in_sub, float in_mul, const float* out_scale, void* stream) {
     E2E_REQUIRE(dz && src0 && dw && workspace && B > 0 && Cin > 0 && Cout > 0, E2E_ERR_ARG, "e2e_conv2d_bwd_weight: bad argument");
     const int vec = (Cin % 4 == 0 && C1 % 4 == 0) ? 4 : 1;
     E2E_REQUIRE(vec == 4 || (C1 == Cin && up == 1 && pad_mode == 0), E2E_ERR_ARG, "e2e_conv2d_bwd_weight: scalar path takes one full-resolution zero-padded source");
@@ -1236,10 +1435,28 @@ int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1,
         if (vec == 4) hipLaunchKernelGGL((k_wgrad_gemm<2, 2, 4>), g, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_wgrad_gemm<2, 2, 1>), g, dim3(256), 0, st, a);
     }
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(egrid((int64_t)Cout * a.Ngemm * 4)), dim3(256), 0, st, workspace, Sz, a.Mpad, a.Npad, Cout, Cin, KH,
-                       KW, a.has_bias, dw, dbias, accumulate);
+    if (Sz >= 16)
+        hipLaunchKernelGGL((k_wgrad_reduce<16>), dim3(egrid((int64_t)Cout * a.Ngemm * 4)), dim3(1024), 0, st, workspace, Sz, a.Mpad, a.Npad, Cout, Cin,
+                           KH, KW, a.has_bias, dw, dbias, accumulate, out_scale);
+    else
+        hipLaunchKernelGGL((k_wgrad_reduce<4>), dim3(egrid((int64_t)Cout * a.Ngemm * 4)), dim3(256), 0, st, workspace, Sz, a.Mpad, a.Npad, Cout, Cin,
+                           KH, KW, a.has_bias, dw, dbias, accumulate, out_scale);
     E2E_LAUNCH_CHECK("e2e_conv2d_bwd_weight");
     return E2E_OK;
+}
+
+int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1, int C1, int up, float* dw, float* dbias,
+                          float* workspace, int B, int Hs, int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride,
+                          int pad, int pad_mode, int accumulate, float in_sub, float in_mul, void* stream) {
+    return bwd_weight_impl(dz, src0, src1, C1, up, dw, dbias, workspace, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate,
+                           in_sub, in_mul, nullptr, stream);
+}
+
+int e2e_conv2d_bwd_weight_scaled(const float* da, const float* out_scale, const float* src0, const float* src1, int C1, int up, float* dw,
+                                 float* dbias, float* workspace, int B, int Hs, int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW,
+                                 int stride, int pad, int pad_mode, int accumulate, float in_sub, float in_mul, void* stream) {
+    return bwd_weight_impl(da, src0, src1, C1, up, dw, dbias, workspace, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate,
+                           in_sub, in_mul, out_scale, stream);
 }
 
 }  // extern "C"

@@ -200,18 +200,28 @@ __global__ __launch_bounds__(256) void k_affine_bwd_partial1(const float* __rest
     if (threadIdx.x == 0) { partial[blockIdx.x * 2] = a; partial[blockIdx.x * 2 + 1] = b; }
 }
 
-// stage 2: fixed-order sum over the slices; accumulate != 0 adds to the gradient buffers (flat gradient bucket)
+// stage 2: fixed-order sum over the slices, 64 channels x 4 slice lanes per workgroup (lane w sums s = w, w + 4, ...; the four
+// partial sums are combined in a fixed order); accumulate != 0 adds to the gradient buffers (flat gradient bucket)
 __global__ __launch_bounds__(256) void k_affine_bwd_final(const float* __restrict__ partial, int S, int C, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float sg[4][64], sb[4][64];
+    const int cl = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float g = 0.f, b = 0.f;
-    for (int s = 0; s < S; ++s) {
-        g += partial[(int64_t)s * 2 * C + c];
-        b += partial[(int64_t)s * 2 * C + C + c];
+    if (c < C)
+        for (int s = w; s < S; s += 4) {
+            g += partial[(int64_t)s * 2 * C + c];
+            b += partial[(int64_t)s * 2 * C + C + c];
+        }
+    sg[w][cl] = g;
+    sb[w][cl] = b;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        g = ((sg[0][cl] + sg[1][cl]) + sg[2][cl]) + sg[3][cl];
+        b = ((sb[0][cl] + sb[1][cl]) + sb[2][cl]) + sb[3][cl];
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + g : g;
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + b : b;
     }
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + g : g;
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + b : b;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -288,7 +298,7 @@ int e2e_affine_bwd(const float* dy, const float* z, const float* mean, const flo
         S = (int)((P + pps - 1) / pps);
         hipLaunchKernelGGL(k_affine_bwd_partial, dim3((C + 63) / 64, S), dim3(256), 0, st, dy, z, mean, rstd, P, C, pps, workspace);
     }
-    hipLaunchKernelGGL(k_affine_bwd_final, dim3((C + 255) / 256), dim3(256), 0, st, workspace, S, C, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(k_affine_bwd_final, dim3((C + 63) / 64), dim3(256), 0, st, workspace, S, C, dgamma, dbeta, accumulate);
     E2E_LAUNCH_CHECK("e2e_affine_bwd");
     return E2E_OK;
 }

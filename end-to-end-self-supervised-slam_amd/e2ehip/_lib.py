@@ -86,9 +86,16 @@ SIGNATURES = {
     "e2e_conv_weight_layouts_batched": [c_fp, c_int, c_fp],
     "e2e_conv2d_fwd": [c_fp, c_fp, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp] + [c_int] * 11 + [c_f32, c_f32, c_fp, c_fp],
     "e2e_conv2d_splitk_workspace_floats": [c_i64, c_int, c_int],
+    "e2e_conv_gemm_force": [c_int, c_int, c_int],
+    "e2e_conv_wgrad_target": [c_int],
+    "e2e_conv_gemm_choice": [c_i64, c_int, c_int, c_int, c_int, c_fp],
     "e2e_conv2d_act_bwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp],
     "e2e_conv2d_bwd_data": [c_fp, c_fp, c_int, c_fp] + [c_int] * 12 + [c_fp, c_fp],
     "e2e_conv2d_bwd_data_acc": [c_fp, c_fp, c_int, c_fp] + [c_int] * 13 + [c_fp, c_fp],
+    "e2e_conv2d_bwd_data_fused": [c_fp, c_fp, c_int, c_fp] + [c_int] * 13 + [c_fp, c_int, c_fp, c_fp],
+    "e2e_conv2d_gather_adjoint_act": [c_fp] + [c_int] * 7 + [c_fp, c_fp, c_int, c_int, c_fp, c_int, c_fp, c_int, c_fp],
+    "e2e_conv2d_bwd_weight_scaled": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp] + [c_int] * 13 + [c_f32, c_f32, c_fp],
+    "e2e_head_bwd_act": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp],
     "e2e_conv2d_act_bwd_acc": [c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_int, c_fp],
     "e2e_conv2d_gather_adjoint": [c_fp] + [c_int] * 7 + [c_fp, c_fp, c_int, c_int, c_fp],
     "e2e_conv2d_wgrad_workspace_floats": [c_int] * 8,

@@ -7,6 +7,13 @@ depth_estimation/networks.py:44-57 (encoder), :277-292 (decoder) and of `loss.ba
 and is the cross-check in tests/test_gpu_netplan.py.
 
 Backward conventions
+  * every gradient buffer holds d loss / d PRE-activation of the layer that produced its tensor ("dA"), not d loss / d output:
+    whoever contributes to the gradient of a tensor x = act(u) multiplies its contribution by act'(u) -- recovered from x,
+    which the contributor reads anyway -- inside its own epilogue (e2e_conv2d_bwd_data_fused, e2e_conv2d_gather_adjoint_act,
+    e2e_head_bwd_act, e2e_maxpool3x3s2_bwd's mul_relu).  A layer's backward GEMMs therefore read its gradient buffer as is;
+    a folded BatchNorm scale rides in the backward weight layout (dX = dA (scale W)^T) and in the backward-weight slab
+    reduction (dW = scale * dA^T X).  The separate dY * act'(Y) [* scale] pass of every layer (round 1 / the autograd
+    path: 0.4 ms of a 6.9 ms step) does not exist;
   * every tensor with several consumers (a BasicBlock's input: first convolution + residual add [+ downsample branch]; the
     encoder features that also feed decoder skips; the stem output: max-pool + last skip) owns ONE gradient buffer; the
     first contribution of a backward pass stores, later ones accumulate inside the producing kernel (accumulate flags of
@@ -28,10 +35,11 @@ _f32 = torch.float32
 
 class Buf:
     """An NHWC activation (B,h,w,C) with its gradient buffer."""
-    __slots__ = ("t", "g", "written", "B", "h", "w", "C")
+    __slots__ = ("t", "g", "written", "B", "h", "w", "C", "act")
 
-    def __init__(self, B, h, w, C, dev, need_grad=True):
+    def __init__(self, B, h, w, C, dev, need_grad=True, act=0):
         self.B, self.h, self.w, self.C = B, h, w, C
+        self.act = act                                  # activation of the producing layer (ACT code): its derivative is taken from t
         self.t = torch.empty(B, h, w, C, device=dev, dtype=_f32)
         self.g = torch.empty(B, h, w, C, device=dev, dtype=_f32) if need_grad else None
         self.written = False
@@ -63,7 +71,9 @@ class _Conv:
         B = src0.B
         self.Hs, self.Ws = src0.h * up, src0.w * up
         self.Ho, self.Wo = (self.Hs + 2 * pad - self.KH) // stride + 1, (self.Ws + 2 * pad - self.KW) // stride + 1
-        self.out = Buf(B, self.Ho, self.Wo, self.Cout, dev)
+        if self.act not in (0, ACT["relu"], ACT["elu"]):
+            raise NotImplementedError("launch plan: convolution epilogues are none / ReLU / ELU (the sigmoid head has its own op)")
+        self.out = Buf(B, self.Ho, self.Wo, self.Cout, dev, act=self.act)
         self.ldf, self.ldb = _ld(self.Cout), _ld(self.Cin)
         self.wf = torch.zeros(self.KH * self.KW * self.Cin, self.ldf, device=dev, dtype=_f32)
         self.need_dx = src0.g is not None
@@ -80,8 +90,6 @@ class _Conv:
         self.ws_f = torch.empty(n, device=dev, dtype=_f32) if n else None
         self.pp = pad if self.pm == 1 else 0
         self.direct = self.pp == 0 and up == 1 and src1 is None
-        n_el = self.out.t.numel()
-        self.dZ = torch.empty(n_el, device=dev, dtype=_f32) if (self.act != 0 or self.scale is not None) else None
         if self.need_dx:
             n = lib.e2e_conv2d_splitk_workspace_floats(B * (self.Hs + 2 * self.pp) * (self.Ws + 2 * self.pp), self.Cin, self.KH * self.KW * self.Cout)
             self.ws_b = torch.empty(n, device=dev, dtype=_f32) if n else None
@@ -91,7 +99,7 @@ class _Conv:
 
     def layout_row(self):
         return [self.weight.data_ptr(), self.wf.data_ptr(), self.wb.data_ptr() if self.wb is not None else 0, self.Cout, self.Cin, self.KH, self.KW,
-                self.ldf, self.ldb, 0]
+                self.ldf, self.ldb, self.scale.data_ptr() if (self.scale is not None and self.wb is not None) else 0]
 
     def fwd(self, plan, st):
         s = self
@@ -102,30 +110,27 @@ class _Conv:
     def bwd(self, plan, st):
         s = self
         B, n = s.src0.B, s.out.t.numel()
-        g = s.out.g
-        if s.res is not None:                       # residual branch: d res (+)= dY * act'(Y)
-            L.call("e2e_conv2d_act_bwd_acc", L.ptr(g), L.ptr(s.out.t), None, L.ptr(s.res.g), n, s.Cout, s.act, 1 if s.res.written else 0, st)
+        g = s.out.g                                 # d loss / d (pre-activation of this layer)
+        if s.res is not None:                       # residual branch: its tensor's pre-activation gradient (+)= g * act_res'(.)
+            L.call("e2e_conv2d_act_bwd_acc", L.ptr(g), L.ptr(s.res.t), None, L.ptr(s.res.g), n, s.Cout, s.res.act, 1 if s.res.written else 0, st)
             s.res.written = True
-        dz = g
-        if s.dZ is not None:                        # dZ = dY * act'(Y) * scale: gradient of the convolution output
-            L.call("e2e_conv2d_act_bwd", L.ptr(g), L.ptr(s.out.t), L.ptr(s.scale), L.ptr(s.dZ), n, s.Cout, s.act, st)
-            dz = s.dZ
         if s.need_dx:
             if s.direct:
-                L.call("e2e_conv2d_bwd_data_acc", L.ptr(dz), L.ptr(s.wb), s.ldb, L.ptr(s.src0.g), B, s.Hs, s.Ws, s.Cin, s.Cout, s.Ho, s.Wo, s.KH, s.KW,
-                       s.stride, s.pad, s.pm, 1 if s.src0.written else 0, L.ptr(s.ws_b), st)
+                L.call("e2e_conv2d_bwd_data_fused", L.ptr(g), L.ptr(s.wb), s.ldb, L.ptr(s.src0.g), B, s.Hs, s.Ws, s.Cin, s.Cout, s.Ho, s.Wo, s.KH, s.KW,
+                       s.stride, s.pad, s.pm, 1 if s.src0.written else 0, L.ptr(s.src0.t), s.src0.act, L.ptr(s.ws_b), st)
                 s.src0.written = True
             else:
-                L.call("e2e_conv2d_bwd_data", L.ptr(dz), L.ptr(s.wb), s.ldb, L.ptr(s.dxp), B, s.Hs, s.Ws, s.Cin, s.Cout, s.Ho, s.Wo, s.KH, s.KW, s.stride,
+                L.call("e2e_conv2d_bwd_data", L.ptr(g), L.ptr(s.wb), s.ldb, L.ptr(s.dxp), B, s.Hs, s.Ws, s.Cin, s.Cout, s.Ho, s.Wo, s.KH, s.KW, s.stride,
                        s.pad, s.pm, L.ptr(s.ws_b), st)
                 s1 = s.src1
-                L.call("e2e_conv2d_gather_adjoint", L.ptr(s.dxp), B, s.Hs, s.Ws, s.Cin, s.C1, s.up, 1 if s.pp else 0, L.ptr(s.src0.g),
-                       L.ptr(s1.g) if s1 is not None else None, 1 if s.src0.written else 0, 1 if (s1 is not None and s1.written) else 0, st)
+                L.call("e2e_conv2d_gather_adjoint_act", L.ptr(s.dxp), B, s.Hs, s.Ws, s.Cin, s.C1, s.up, 1 if s.pp else 0, L.ptr(s.src0.g),
+                       L.ptr(s1.g) if s1 is not None else None, 1 if s.src0.written else 0, 1 if (s1 is not None and s1.written) else 0,
+                       L.ptr(s.src0.t), s.src0.act, L.ptr(s1.t) if s1 is not None else None, s1.act if s1 is not None else 0, st)
                 s.src0.written = True
                 if s1 is not None:
                     s1.written = True
         st_w = plan.fork(st)
-        L.call("e2e_conv2d_bwd_weight", L.ptr(dz), L.ptr(s.src0.t), L.ptr(s.src1.t) if s.src1 is not None else None, s.C1, s.up,
+        L.call("e2e_conv2d_bwd_weight_scaled", L.ptr(g), L.ptr(s.scale), L.ptr(s.src0.t), L.ptr(s.src1.t) if s.src1 is not None else None, s.C1, s.up,
                L.ptr(plan.sink(s.weight)), L.ptr(plan.sink(s.bias)) if s.bias is not None else None, L.ptr(s.ws_w), B, s.Hs, s.Ws, s.Cin, s.Cout, s.Ho,
                s.Wo, s.KH, s.KW, s.stride, s.pad, s.pm, 0, float(s.isub), float(s.imul), st_w)
 
@@ -148,8 +153,8 @@ class _Head:
         L.call("e2e_conv2d_act_bwd", L.ptr(self.out.g), L.ptr(self.out.t), None, L.ptr(self.dz), n, 1, self.act, st)
         if s.written:
             raise RuntimeError("the disparity head's input has a single consumer")
-        L.call("e2e_head_bwd", L.ptr(self.dz), L.ptr(s.t), L.ptr(self.weight), L.ptr(s.g), L.ptr(plan.sink(self.weight)),
-               L.ptr(plan.sink(self.bias)) if self.bias is not None else None, L.ptr(self.ws), s.B, s.h, s.w, s.C, st)
+        L.call("e2e_head_bwd_act", L.ptr(self.dz), L.ptr(s.t), L.ptr(self.weight), L.ptr(s.g), L.ptr(plan.sink(self.weight)),
+               L.ptr(plan.sink(self.bias)) if self.bias is not None else None, L.ptr(self.ws), s.B, s.h, s.w, s.C, s.act, st)
         s.written = True
 
 
@@ -164,7 +169,9 @@ class _MaxPool:
 
     def bwd(self, plan, st):
         s = self.src
-        L.call("e2e_maxpool3x3s2_bwd", L.ptr(s.t), L.ptr(self.out.g), L.ptr(s.g), s.B, s.h, s.w, s.C, 1 if s.written else 0, 0, st)
+        if s.act not in (0, ACT["relu"]):
+            raise NotImplementedError("launch plan: the max-pool follows a ReLU (ResNet stem)")
+        L.call("e2e_maxpool3x3s2_bwd", L.ptr(s.t), L.ptr(self.out.g), L.ptr(s.g), s.B, s.h, s.w, s.C, 1 if s.written else 0, 1 if s.act else 0, st)
         s.written = True
 
 
@@ -189,6 +196,8 @@ class _BNAffine:
         n = s.t.numel()
         L.call("e2e_affine_bwd", L.ptr(self.out.g), L.ptr(s.t), L.ptr(b.running_mean), L.ptr(self.rstd), n // s.C, s.C, L.ptr(plan.sink(b.weight)),
                L.ptr(plan.sink(b.bias)), 0, L.ptr(self.ws), st)
+        if s.act != 0:
+            raise NotImplementedError("launch plan: a trainable BatchNorm follows a plain convolution")
         L.call("e2e_conv2d_act_bwd_acc", L.ptr(self.out.g), L.ptr(self.out.g), L.ptr(self.scale), L.ptr(s.g), n, s.C, 0, 1 if s.written else 0, st)
         s.written = True
 

@@ -21,11 +21,14 @@ def _conv_flops(name, a):
         B, Hs, Ws, Cin, Cout, KH, KW, stride, pad = a[10:19]
         Ho, Wo = (Hs + 2 * pad - KH) // stride + 1, (Ws + 2 * pad - KW) // stride + 1
         return 2.0 * B * Ho * Wo * Cout * Cin * KH * KW
-    if name in ("e2e_conv2d_bwd_data", "e2e_conv2d_bwd_data_acc"):
+    if name in ("e2e_conv2d_bwd_data", "e2e_conv2d_bwd_data_acc", "e2e_conv2d_bwd_data_fused"):
         B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW = a[4:13]
         return 2.0 * B * Ho * Wo * Cout * Cin * KH * KW
     if name == "e2e_conv2d_bwd_weight":
         B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW = a[8:17]
+        return 2.0 * B * Ho * Wo * Cout * Cin * KH * KW
+    if name == "e2e_conv2d_bwd_weight_scaled":
+        B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW = a[9:18]
         return 2.0 * B * Ho * Wo * Cout * Cin * KH * KW
     return 0.0
 

@@ -328,6 +328,7 @@ int e2e_conv_weight_layouts(const float* w, int Cout, int Cin, int KH, int KW, f
  * step).  `desc`: DEVICE array of 10 int64 per layer {w, w_fwd, w_bwd (addresses, 0 = skip), Cout,
  * Cin, KH, KW, ld_fwd, ld_bwd, 0}. */
 int e2e_conv_weight_layouts_batched(const long long* desc, int nlayers, void* stream);
+/* (descriptor slot 9, "reserved" in round 1: a float* per-output-channel factor folded into w_bwd only, or 0) */
 
 /* out (B,Ho,Wo,Cout) = act( scale[c] * conv(x) + shift[c] (+ residual) ), x = the VIRTUAL input
  * cat( nearest_upsample(src0 (B,Hs/up,Ws/up,C1), up), src1 (B,Hs,Ws,Cin-C1) ) padded by `pad`
@@ -344,6 +345,15 @@ int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const f
  * slices in a fixed order.  workspace for e2e_conv2d_fwd (rows = B*Ho*Wo, cols = Cout, K = KH*KW*Cin)
  * and e2e_conv2d_bwd_data (rows = B*(Hs+2p)*(Ws+2p), cols = Cin, K = KH*KW*Cout); NULL disables it. */
 int64_t e2e_conv2d_splitk_workspace_floats(int64_t rows, int cols, int K);
+/* Tuning hook (tools/gemm_tune.py): force the workgroup tile (bm x bn in {64x64, 128x64, 128x128, 128x32, 32x128, 32x64,
+ * 64x32, 32x32}) and the number of K slices of every following convolution GEMM; bm = 0 restores the built-in choice
+ * (a cost model over tile quantisation on 256 CUs, calibrated with that tool).  Query the split-K workspace AFTER forcing. */
+int e2e_conv_gemm_force(int bm, int bn, int ksplit);
+/* tuning hook of the backward-weight GEMM: the number of workgroups its pixel slices are spread over (default 1024);
+ * query e2e_conv2d_wgrad_workspace_floats AFTER changing it. */
+int e2e_conv_wgrad_target(int workgroups);
+/* host-only query of that choice: out3 (HOST pointer) = {bm, bn, K slices}. */
+int e2e_conv_gemm_choice(int64_t rows, int cols, int K, int chunk_depth, int allow_split, int* out3_host);
 
 /* dZ = dY * act'(Y) * scale[c]  (Y = the op's OUTPUT; scale may be NULL). */
 int e2e_conv2d_act_bwd(const float* dy, const float* y, const float* scale, float* dz, int64_t n,
@@ -362,11 +372,27 @@ int e2e_conv2d_bwd_data(const float* dz, const float* w_bwd, int ld_bwd, float* 
 int e2e_conv2d_bwd_data_acc(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs,
                             int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride,
                             int pad, int pad_mode, int accumulate, float* workspace, void* stream);
+/* Backward-data for the launch plan of a whole network (e2ehip.netplan), which keeps d loss / d PRE-activation in every gradient
+ * buffer: `da` is that gradient of this layer's output (no separate dY * act'(Y) pass; a folded BatchNorm scale is folded into
+ * w_bwd by e2e_conv_weight_layouts_batched), and with in_act = 1 (ReLU) / 2 (ELU) the epilogue multiplies the result by
+ * act'(.) of the tensor x_in (B,Hs,Ws,Cin) the forward convolution read, so dxp is already the pre-activation gradient of the
+ * layer that produced x_in (pad_mode 0 only; reflection-padded layers apply it in e2e_conv2d_gather_adjoint_act). */
+int e2e_conv2d_bwd_data_fused(const float* da, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs,
+                              int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride,
+                              int pad, int pad_mode, int accumulate, const float* x_in, int in_act,
+                              float* workspace, void* stream);
 /* adjoint of the gather: dxp -> d_src0 (B,Hs/up,Ws/up,C1) [, d_src1 (B,Hs,Ws,Cin-C1)]; every output
  * element sums its reflect-pad copies and its up x up readers in a fixed order (no atomics). */
 int e2e_conv2d_gather_adjoint(const float* dxp, int B, int Hs, int Ws, int Cin, int C1, int up,
                               int padded, float* d_src0, float* d_src1, int accumulate0,
                               int accumulate1, void* stream);
+
+/* the same, each destination multiplied by act'(.) of the tensor it is the gradient of (src0 (B,Hs/up,Ws/up,C1) with act0, src1
+ * (B,Hs,Ws,Cin-C1) with act1; 0 none, 1 ReLU, 2 ELU -- derivative taken from the activation's output). */
+int e2e_conv2d_gather_adjoint_act(const float* dxp, int B, int Hs, int Ws, int Cin, int C1, int up,
+                                  int padded, float* d_src0, float* d_src1, int accumulate0,
+                                  int accumulate1, const float* src0, int act0, const float* src1,
+                                  int act1, void* stream);
 
 /* dW (Cout,Cin,KH,KW) [and dbias (Cout) when non-NULL] = split-K GEMM over the output pixels with a
  * fixed-order slab reduction.  workspace: e2e_conv2d_wgrad_workspace_floats(...) floats. */
@@ -376,6 +402,14 @@ int e2e_conv2d_bwd_weight(const float* dz, const float* src0, const float* src1,
                           float* dw, float* dbias, float* workspace, int B, int Hs, int Ws, int Cin,
                           int Cout, int Ho, int Wo, int KH, int KW, int stride, int pad,
                           int pad_mode, int accumulate, float in_sub, float in_mul, void* stream);
+
+/* the same on `da` = the gradient BEFORE a folded BatchNorm scale: dW[co] = out_scale[co] * sum_p da[p,co] x[p,...] (the scale is
+ * applied once per output element in the slab reduction instead of once per pixel in a separate pass); out_scale may be NULL. */
+int e2e_conv2d_bwd_weight_scaled(const float* da, const float* out_scale, const float* src0,
+                                 const float* src1, int C1, int up, float* dw, float* dbias,
+                                 float* workspace, int B, int Hs, int Ws, int Cin, int Cout, int Ho,
+                                 int Wo, int KH, int KW, int stride, int pad, int pad_mode,
+                                 int accumulate, float in_sub, float in_mul, void* stream);
 
 /* ResNet stem max-pool, nn.MaxPool2d(3, 2, 1) (networks.py:53 -> torchvision resnet.maxpool): x (B,H,W,C) NHWC ->
  * y (B,(H-1)/2+1,(W-1)/2+1,C).  The backward keeps no index tensor: every input element re-derives the first maximum
@@ -416,6 +450,11 @@ int e2e_head_fwd(const float* x, const float* w, const float* bias, float* y, in
 int64_t e2e_head_workspace_floats(void);
 int e2e_head_bwd(const float* dz, const float* x, const float* w, float* dx, float* dw, float* dbias,
                  float* workspace, int B, int H, int W, int Cin, void* stream);
+
+/* e2e_head_bwd whose dx is multiplied by act'(x) (in_act 1 ReLU / 2 ELU, from the activation's output x): the pre-activation
+ * gradient of the layer that produced x (launch plan form, see e2e_conv2d_bwd_data_fused). */
+int e2e_head_bwd_act(const float* dz, const float* x, const float* w, float* dx, float* dw, float* dbias,
+                     float* workspace, int B, int H, int W, int Cin, int in_act, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Frame-to-model ICP odometry (gradslam odometry providers; MODEL.odom: icp | gradicp)          */

@@ -53,3 +53,46 @@ def test_batch_of_two_equals_two_calls(golden):
         b = m(colors[:, 1], 1)[("disp", 1, 0)]
         both = m(colors[0], 0)[("disp", 0, 0)]
     torch.testing.assert_close(both, torch.cat([a, b], 0), rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_pair_forward_backward_vs_oracle():
+    """The shipped size: a 480x640 keyframe pair as one batch of 2 through the network, forward and backward, on the GPU (both the
+    nn.Module path and the static launch plan of the driver) against the CPU oracle -- this is what exercises the large-grid GEMM
+    decompositions (128-row tiles, thin 32-column tiles, parity-class backward, split-K) that 64x96 inputs never select."""
+    from e2ehip.netplan import NetPlan
+    from e2ehip.synthetic import make_sequence
+    H, W = 480, 640
+    colors = make_sequence(2, H, W, seed=21)[0][0]                   # (2,H,W,3)
+    g = torch.Generator().manual_seed(3)
+    wgt = torch.randn(2, 1, H, W, generator=g) / (H * W)
+    sd = depthnet.random_state_dict(0)
+    # --- CPU oracle ---------------------------------------------------------------------------------------------------
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    keys = depthnet.trainable_keys(sd)
+    sd_o = {k: (v.clone().requires_grad_(True) if k in keys else v.clone()) for k, v in sd.items()}
+    disp_o = depthnet.disp_forward(sd_o, colors)
+    (disp_o * wgt).sum().backward()
+    # --- nn.Module path -----------------------------------------------------------------------------------------------
+    m = _model()
+    disp = m(colors.to(DEV), 0)[("disp", 0, 0)]
+    torch.testing.assert_close(disp.detach().cpu(), disp_o.detach(), rtol=1e-4, atol=1e-5)
+    (disp * wgt.to(DEV)).sum().backward()
+    params = dict(m.named_parameters())
+    for k in keys:
+        a, b = params[k].grad.cpu(), sd_o[k].grad
+        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+        assert err < 1e-3, (k, err)                                 # gradients: 1e-3 of the tensor's max (DESIGN.md section 5)
+        torch.testing.assert_close(a.norm(), b.norm(), rtol=1e-4, atol=1e-9)
+    # --- launch plan --------------------------------------------------------------------------------------------------
+    for p in m.parameters():
+        p.grad = None
+    plan = NetPlan(m, 2, H, W, DEV, overlap=True)
+    plan.refresh_layouts()
+    d2 = plan.forward(colors.to(DEV))
+    assert torch.equal(d2, disp.detach())
+    plan.backward(wgt.to(DEV))
+    torch.cuda.synchronize()
+    for k in keys:
+        a, b = plan.sink(params[k]).cpu(), sd_o[k].grad
+        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+        assert err < 1e-3, (k, err)
