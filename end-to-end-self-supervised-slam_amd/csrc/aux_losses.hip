@@ -248,7 +248,106 @@ __global__ __launch_bounds__(AT) void k_masked_mean_grad(const float* __restrict
     for (int64_t i = (int64_t)blockIdx.x * AT + threadIdx.x; i < n; i += (int64_t)gridDim.x * AT) g[i] = gate[i] != 0.f ? k : 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// small image-space helpers of train_depth.py's operator-by-operator loss assembly (off the fused path):
+//   * prediction * valid_mask with the mask broadcast over channels (train_depth.py:713-714), strided input read in place
+//   * mean over the channel axis of stacked photometric maps (`photmetric.mean(1, keepdim=True)`, :630) and its adjoint
+//   * disp / (mean_hw(disp) + 1e-7) (:768-770) and its adjoint (two fixed-order reductions per image)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AT) void k_mask_mul(const float* __restrict__ x, e2e_strides xs, const float* __restrict__ mask, int B, int C, int H, int W,
+                                                 float* __restrict__ out) {
+    const int64_t n = (int64_t)B * C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * AT + threadIdx.x; i < n; i += (int64_t)gridDim.x * AT) {
+        int64_t t = i;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H); t /= H;
+        const int c = (int)(t % C); t /= C;
+        const int b = (int)t;
+        out[i] = x[b * xs.sb + c * xs.sc + h * xs.sh + w * xs.sw] * mask[((int64_t)b * H + h) * W + w];
+    }
+}
+
+// fwd: out[b,0,p] = mean_c x[b,c,p] ; bwd (adjoint != 0): out[b,c,p] = x[b,0,p] / C
+__global__ __launch_bounds__(AT) void k_channel_mean(const float* __restrict__ x, int B, int C, int64_t HW, int adjoint, float* __restrict__ out) {
+    const int64_t n = adjoint ? (int64_t)B * C * HW : (int64_t)B * HW;
+    const float inv = 1.f / (float)C;
+    for (int64_t i = (int64_t)blockIdx.x * AT + threadIdx.x; i < n; i += (int64_t)gridDim.x * AT) {
+        if (adjoint) {
+            const int64_t b = i / ((int64_t)C * HW), p = i % HW;
+            out[i] = x[b * HW + p] * inv;
+        } else {
+            const int64_t b = i / HW, p = i - b * HW;
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) s += x[(b * C + c) * HW + p];
+            out[i] = s * inv;
+        }
+    }
+}
+
+// per image b: partial sums of a[i] (and of a[i] * b2[i] when b2 != NULL) over its HW elements; grid = (parts, B)
+__global__ __launch_bounds__(AT) void k_image_sums(const float* __restrict__ a, const float* __restrict__ b2, int64_t HW, float* __restrict__ partials) {
+    __shared__ float red[AT / 64];
+    const float* ab = a + (int64_t)blockIdx.y * HW;
+    const float* bb = b2 ? b2 + (int64_t)blockIdx.y * HW : nullptr;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * AT + threadIdx.x; i < HW; i += (int64_t)gridDim.x * AT) s += bb ? ab[i] * bb[i] : ab[i];
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.y * gridDim.x + blockIdx.x] = t;
+}
+__global__ __launch_bounds__(64) void k_image_sums_final(const float* __restrict__ partials, int nparts, float* __restrict__ out) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) v += (double)partials[blockIdx.x * nparts + i];
+    v = wave_sum_d(v);
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)v;
+}
+// fwd: out = d / (mean + 1e-7), mean = sum[b] / HW ; bwd: out = g / (m + eps) - sum(g d)[b] / (HW (m + eps)^2)
+__global__ __launch_bounds__(AT) void k_mean_normalize(const float* __restrict__ d, const float* __restrict__ g, const float* __restrict__ sum_d,
+                                                       const float* __restrict__ sum_gd, int B, int64_t HW, float* __restrict__ out) {
+    const int64_t n = (int64_t)B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * AT + threadIdx.x; i < n; i += (int64_t)gridDim.x * AT) {
+        const int b = (int)(i / HW);
+        const float den = sum_d[b] / (float)HW + 1e-7f;
+        out[i] = g ? g[i] / den - sum_gd[b] / ((float)HW * den * den) : d[i] / den;
+    }
+}
+
 extern "C" {
+
+int e2e_mask_mul(const float* x, e2e_strides x_strides, const float* mask, int B, int C, int H, int W, float* out, void* stream) {
+    E2E_REQUIRE(x && mask && out && B > 0 && C > 0 && H > 0 && W > 0, E2E_ERR_ARG, "e2e_mask_mul: bad argument");
+    hipLaunchKernelGGL(k_mask_mul, dim3(agrid((int64_t)B * C * H * W, 2048)), dim3(AT), 0, (hipStream_t)stream, x, x_strides, mask, B, C, H, W, out);
+    E2E_LAUNCH_CHECK("e2e_mask_mul");
+    return E2E_OK;
+}
+
+int e2e_channel_mean(const float* x, int B, int C, int H, int W, int adjoint, float* out, void* stream) {
+    E2E_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0, E2E_ERR_ARG, "e2e_channel_mean: bad argument");
+    const int64_t n = (int64_t)B * (adjoint ? C : 1) * H * W;
+    hipLaunchKernelGGL(k_channel_mean, dim3(agrid(n, 2048)), dim3(AT), 0, (hipStream_t)stream, x, B, C, (int64_t)H * W, adjoint, out);
+    E2E_LAUNCH_CHECK("e2e_channel_mean");
+    return E2E_OK;
+}
+
+/* workspace: B * (2 * 64 + 2) floats.  g == NULL: forward (out = d / (mean_hw d + 1e-7)); else the adjoint for upstream gradient g. */
+int e2e_mean_normalize(const float* d, const float* g, int B, int H, int W, float* out, float* workspace, void* stream) {
+    E2E_REQUIRE(d && out && workspace && B > 0 && H > 0 && W > 0, E2E_ERR_ARG, "e2e_mean_normalize: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t HW = (int64_t)H * W;
+    const int parts = 64;
+    float* p0 = workspace;                    // [B][parts]
+    float* p1 = workspace + (int64_t)B * parts;
+    float* s0 = p1 + (int64_t)B * parts;      // [B]
+    float* s1 = s0 + B;
+    hipLaunchKernelGGL(k_image_sums, dim3(parts, B), dim3(AT), 0, st, d, (const float*)nullptr, HW, p0);
+    hipLaunchKernelGGL(k_image_sums_final, dim3(B), dim3(64), 0, st, p0, parts, s0);
+    if (g) {
+        hipLaunchKernelGGL(k_image_sums, dim3(parts, B), dim3(AT), 0, st, g, d, HW, p1);
+        hipLaunchKernelGGL(k_image_sums_final, dim3(B), dim3(64), 0, st, p1, parts, s1);
+    }
+    hipLaunchKernelGGL(k_mean_normalize, dim3(agrid((int64_t)B * HW, 2048)), dim3(AT), 0, st, d, g, s0, s1, B, HW, out);
+    E2E_LAUNCH_CHECK("e2e_mean_normalize");
+    return E2E_OK;
+}
 
 int e2e_masked_mean_lossgrad(const float* values, const float* gate, int64_t n, float weight, float* out3, float* g_values, float* workspace,
                              void* stream) {

@@ -338,6 +338,38 @@ int e2e_depth_scale_fwd(const float* disp, const float* median_gt, float* delta,
     return E2E_OK;
 }
 
+// fixed scale (train_depth.py:343-345: depth = 1 / disp, then `*= ABLATION.scaling_depth`): delta = 1 / disp, depth = delta * scale, in the
+// reference's operation order; backward g_disp = -(g_depth * scale) * delta * delta
+__global__ __launch_bounds__(DT) void k_fixed_scale_fwd(const float* __restrict__ disp, float scale, float* __restrict__ delta, float* __restrict__ depth,
+                                                        int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT) {
+        const float d = 1.f / disp[i];
+        if (delta) delta[i] = d;
+        depth[i] = d * scale;
+    }
+}
+__global__ __launch_bounds__(DT) void k_fixed_scale_bwd(const float* __restrict__ g_depth, const float* __restrict__ disp, float scale,
+                                                        float* __restrict__ g_disp, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT) {
+        const float d = 1.f / disp[i];
+        g_disp[i] = -(g_depth[i] * scale) * d * d;
+    }
+}
+
+int e2e_depth_fixed_scale_fwd(const float* disp, float scale, float* delta, float* depth, int64_t n, void* stream) {
+    E2E_REQUIRE(n > 0 && disp && depth, E2E_ERR_ARG, "e2e_depth_fixed_scale_fwd: bad argument");
+    hipLaunchKernelGGL(k_fixed_scale_fwd, dim3(sgrid(n)), dim3(DT), 0, (hipStream_t)stream, disp, scale, delta, depth, n);
+    E2E_LAUNCH_CHECK("e2e_depth_fixed_scale_fwd");
+    return E2E_OK;
+}
+
+int e2e_depth_fixed_scale_bwd(const float* g_depth, const float* disp, float scale, float* g_disp, int64_t n, void* stream) {
+    E2E_REQUIRE(n > 0 && g_depth && disp && g_disp, E2E_ERR_ARG, "e2e_depth_fixed_scale_bwd: bad argument");
+    hipLaunchKernelGGL(k_fixed_scale_bwd, dim3(sgrid(n)), dim3(DT), 0, (hipStream_t)stream, g_depth, disp, scale, g_disp, n);
+    E2E_LAUNCH_CHECK("e2e_depth_fixed_scale_bwd");
+    return E2E_OK;
+}
+
 int e2e_depth_scale_bwd(const float* g_depth, const float* delta, const float* median_gt, const float* median_delta,
                         float* g_disp, void* workspace, int64_t n, void* stream) {
     E2E_REQUIRE(n > 0 && g_depth && delta && median_gt && median_delta && g_disp && workspace, E2E_ERR_ARG, "e2e_depth_scale_bwd: bad argument");

@@ -67,6 +67,8 @@ SIGNATURES = {
     "e2e_depth_scale_workspace_bytes": [],
     "e2e_depth_scale_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp],
     "e2e_depth_scale_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp],
+    "e2e_depth_fixed_scale_fwd": [c_fp, c_f32, c_fp, c_fp, c_i64, c_fp],
+    "e2e_depth_fixed_scale_bwd": [c_fp, c_fp, c_f32, c_fp, c_i64, c_fp],
     "e2e_reduce_workspace_floats": [],
     "e2e_mean_diff_fwd": [c_fp, c_fp, c_i64, c_int, c_fp, c_fp, c_fp],
     "e2e_mean_diff_bwd": [c_fp, c_fp, c_fp, c_i64, c_int, c_fp, c_fp],
@@ -74,6 +76,9 @@ SIGNATURES = {
     "e2e_adam_step": [c_fp, c_fp, c_fp, c_fp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_fp],
     "e2e_adam_step_mean": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_fp],
     "e2e_adam_step_resident": [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f32, c_f32, c_f32, c_fp, c_int, c_fp, c_fp],
+    "e2e_mask_mul": [c_fp, Strides, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp],
+    "e2e_channel_mean": [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp],
+    "e2e_mean_normalize": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "e2e_masked_mean_lossgrad": [c_fp, c_fp, c_i64, c_f32, c_fp, c_fp, c_fp, c_fp],
     "e2e_aux_workspace_floats": [],
     "e2e_smoothness_lossgrad": [c_fp, c_fp, Strides, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],

@@ -473,6 +473,31 @@ def depth_from_disp_median_scaled(disp, median_gt):
     return _DepthScale.apply(disp, median_gt)
 
 
+class _FixedScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, scale):
+        d = L.dev(disp, "disp").contiguous()
+        depth = torch.empty_like(d)
+        L.call("e2e_depth_fixed_scale_fwd", L.ptr(d), float(scale), None, L.ptr(depth), d.numel(), L.stream())
+        ctx.save_for_backward(d)
+        ctx.scale = float(scale)
+        return depth
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        gd = torch.empty_like(d)
+        L.call("e2e_depth_fixed_scale_bwd", L.ptr(g.contiguous()), L.ptr(d), ctx.scale, L.ptr(gd), d.numel(), L.stream())
+        return gd, None
+
+
+def depth_from_disp_fixed_scale(disp, scale=1.0):
+    """depth = (1 / disp) * scale (train_depth.py:331, :343-345: the development harness scales by the constant
+    ABLATION.scaling_depth instead of the median ratio); scale 1.0 is the plain `1 / disp`."""
+    return _FixedScale.apply(disp, scale)
+
+
 class _MeanDiff(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, kind):
@@ -656,3 +681,89 @@ class _DispBlend(torch.autograd.Function):
 def process_disparity(disp_pair):
     """train_depth.py:224-237 (dual-disparity post-processing)."""
     return _DispBlend.apply(disp_pair)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# helpers of train_depth.py's operator-by-operator loss assembly
+# ---------------------------------------------------------------------------------------------------------------------
+class _MaskMul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask):
+        x = L.dev(x, "image")
+        B, C, H, W = x.shape
+        m = L.dev(mask, "valid_mask").reshape(B, 1, H, W).contiguous()
+        out = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+        L.call("e2e_mask_mul", L.ptr(x), L.strides4(x), L.ptr(m), B, C, H, W, L.ptr(out), L.stream())
+        ctx.save_for_backward(m)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        g = g.contiguous()
+        B, C, H, W = g.shape
+        gx = torch.empty_like(g)
+        L.call("e2e_mask_mul", L.ptr(g), L.strides4(g), L.ptr(m), B, C, H, W, L.ptr(gx), L.stream())
+        return gx, None
+
+
+def mask_mul(x, mask):
+    """x (B,C,H,W) * mask (B,1,H,W) -- `prediction * valid_mask` of train_depth.py:713-714; the mask carries no gradient."""
+    return _MaskMul.apply(x, mask)
+
+
+class _ChannelMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = L.dev(x, "maps").contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty(B, 1, H, W, device=x.device, dtype=torch.float32)
+        L.call("e2e_channel_mean", L.ptr(x), B, C, H, W, 0, L.ptr(out), L.stream())
+        ctx.C = C
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, _, H, W = g.shape
+        gx = torch.empty(B, ctx.C, H, W, device=g.device, dtype=torch.float32)
+        L.call("e2e_channel_mean", L.ptr(g), B, ctx.C, H, W, 1, L.ptr(gx), L.stream())
+        return gx
+
+
+def channel_mean(x):
+    """x.mean(1, keepdim=True) of stacked photometric maps (train_depth.py:630)."""
+    if x.dim() != 4:
+        raise ValueError("channel_mean expects (B,C,H,W)")
+    return x if x.shape[1] == 1 else _ChannelMean.apply(x)
+
+
+class _MeanNormalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d):
+        d = L.dev(d, "disp").contiguous()
+        B, C, H, W = d.shape
+        out = torch.empty_like(d)
+        ws = torch.empty(B * C * 130, device=d.device, dtype=torch.float32)
+        L.call("e2e_mean_normalize", L.ptr(d), None, B * C, H, W, L.ptr(out), L.ptr(ws), L.stream())
+        ctx.save_for_backward(d)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        B, C, H, W = d.shape
+        gd = torch.empty_like(d)
+        ws = torch.empty(B * C * 130, device=d.device, dtype=torch.float32)
+        L.call("e2e_mean_normalize", L.ptr(d), L.ptr(g.contiguous()), B * C, H, W, L.ptr(gd), L.ptr(ws), L.stream())
+        return gd
+
+
+def mean_normalize(disp):
+    """disp / (disp.mean(2, True).mean(3, True) + 1e-7) (train_depth.py:768-770)."""
+    if disp.dim() != 4:
+        raise ValueError("mean_normalize expects (B,C,H,W)")
+    return _MeanNormalize.apply(disp)

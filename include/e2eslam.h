@@ -277,6 +277,13 @@ int e2e_depth_scale_bwd(const float* g_depth, const float* delta, const float* m
                         const float* median_delta, float* g_disp, void* workspace, int64_t n,
                         void* stream);
 
+/* The fixed-scale form of train_depth.py:331-345 (`depth = 1 / disp` then `depth *= ABLATION.scaling_depth`): delta = 1 / disp
+ * (may be NULL), depth = delta * scale; backward g_disp = -(g_depth * scale) / disp^2. */
+int e2e_depth_fixed_scale_fwd(const float* disp, float scale, float* delta, float* depth, int64_t n,
+                              void* stream);
+int e2e_depth_fixed_scale_bwd(const float* g_depth, const float* disp, float scale, float* g_disp,
+                              int64_t n, void* stream);
+
 /* depth_reguralizer (losses.py:134-148) as a stand-alone op: out = mean |a-b| (kind 1) or
  * mean (a-b)^2 (kind 2); backward wrt b with upstream device scalar g_out.
  * workspace: e2e_reduce_workspace_floats() floats. */
@@ -500,6 +507,17 @@ int e2e_masked_l1_lossgrad(const float* prediction, const float* sparse_gt, cons
  * gradient goes to the first minimal channel. */
 int e2e_min_reprojection_lossgrad(const float* errors, int B, int C, int H, int W, float* loss_out,
                                   float* g_errors, float* workspace, void* stream);
+
+/* train_depth.py's operator-by-operator loss assembly (the fused kernels cover the default flags; these serve min-reprojection /
+ * auto-masking / smoothness):  out (B,C,H,W) = x (strided view) * mask (B,1,H,W) (:713-714);  channel mean of stacked error maps
+ * (B,C,H,W) -> (B,1,H,W) (:630) and its adjoint (adjoint = 1: x (B,1,H,W) -> out (B,C,H,W) = x / C);  mean-normalised disparity
+ * d / (mean_hw(d) + 1e-7) per image (:768-770) and, with g != NULL, its adjoint for the upstream gradient g (workspace: B * 130
+ * floats). */
+int e2e_mask_mul(const float* x, e2e_strides x_strides, const float* mask, int B, int C, int H, int W,
+                 float* out, void* stream);
+int e2e_channel_mean(const float* x, int B, int C, int H, int W, int adjoint, float* out, void* stream);
+int e2e_mean_normalize(const float* d, const float* g, int B, int H, int W, float* out, float* workspace,
+                       void* stream);
 
 /* mean of values[i] over the elements whose gate[i] != 0, and weight x its gradient: the 3-D point loss
  * (online_adaption.py:638-645; loss/losses.py:57-63 `torch.mean(dists)`) over the valid-depth pixels without the
