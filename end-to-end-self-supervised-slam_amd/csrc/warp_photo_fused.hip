@@ -517,8 +517,8 @@ static int lossgrad_impl(const float* depth_tgt, const float* src, e2e_strides s
     E2E_REQUIRE(!reg_kind || (reg_init_tgt && reg_init_src && depth_src && g_depth_src), E2E_ERR_ARG,
                 "e2e_warp_photo_lossgrad: regulariser buffers missing");
     // two rows per thread (32x16 tiles) measured faster than one row (32x8) at both 1 and 8 pairs per launch
-    int ppt = 2;
-    if (const char* ev = getenv("E2E_LOSSGRAD_PPT")) ppt = (ev[0] == '2') ? 2 : 1;   // tuning override
+    // (the one-row variant stays compiled for the A/B in profiles/r01_warp_photo_lossgrad_history.md; no per-launch environment lookup)
+    static const int ppt = [] { const char* ev = getenv("E2E_LOSSGRAD_PPT"); return (ev && ev[0] == '1') ? 1 : 2; }();
     const dim3 g(e2e_ceil_div(W, LT_W), e2e_ceil_div(H, 8 * ppt), B);
     const int nblk = g.x * g.y * g.z;
     // channels-last frames (the reference's memory layout) take the 12-byte-per-tap path

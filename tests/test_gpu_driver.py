@@ -176,3 +176,34 @@ def test_launch_plan_equals_autograd_path_and_graph_replay_is_exact():
     for k in sd_g:
         if sd_g[k].dtype.is_floating_point:
             torch.testing.assert_close(sd_g[k], sd_a[k], rtol=0, atol=2.5e-5, msg=k)     # <= 2 Adam steps of lr 1e-5 apart where a gradient sign is at noise level
+
+
+def test_tum_shaped_sequence_vs_oracle_first_keyframe():
+    """BASELINE configs[3] in small: TUM intrinsics (fx = fy = 525, positive fy), 10 % zero-depth holes in the ground truth,
+    DATA.name TUM (the holes are masked in depth_metrics only, losses.py:167-169; the median of the ground truth includes them,
+    online_adaption.py:295), keyframe threshold 0.12: 3 refinement steps of the first keyframe against the oracle, then the map."""
+    from e2ehip.synthetic import make_sequence, tum_intrinsics
+    from online_adaption import SLAM
+    H, W, L = 64, 96, 3
+    seq = make_sequence(L, H, W, seed=13, step=0.13, K=tum_intrinsics(H, W), holes=0.1)
+    assert float((seq[1] == 0).float().mean()) > 0.05
+    sd = depthnet.random_state_dict(0)
+    cfg = _cfg(H, W, L)
+    cfg.DATA.name = "TUM"
+    cfg.DEMO.frame_threshold = 0.12
+    slam = SLAM(cfg, sequence=seq, state_dict=sd)
+    assert len(slam.keyframe_schedule()) == L - 1                    # 0.13 m steps: every frame is a keyframe at threshold 0.12
+    slam.set_refinement_mode()
+    slam.first_iter = True
+    slam.refinement(0, 1)
+    log = torch.stack(slam.log)
+    colors, gt, K, poses = seq
+    ocfg = refine.Config()
+    ocfg.dataset = "TUM"
+    ora = refine.Refiner(sd, ocfg)
+    recs = ora.refine_pair(colors[:, [0, 1]], gt[:, [0, 1]], poses[:, [0, 1]], K)
+    np.testing.assert_allclose(log[:, 1].numpy(), [r["photometric"] for r in recs], rtol=1e-4)
+    np.testing.assert_allclose(log[:, 2].numpy(), [r["reg"] for r in recs], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(log[:, 3].numpy(), [r["ratio"] for r in recs], rtol=1e-4)
+    np.testing.assert_allclose(log[:, 4:11].numpy(), np.array([r["metrics"] for r in recs]), rtol=2e-4, atol=1e-6)   # masked: holes excluded
+    assert abs(slam.map.M - ora.map["points"].shape[0]) <= 0.002 * slam.map.M

@@ -108,3 +108,32 @@ def test_image_recover_slam_and_icpslam():
     assert cloud.points_list[0].shape[0] == int((depth != 0).sum())
     pc, poses = ICPSLAM(odom="gt", device=DEV)(frames)
     assert tuple(poses.shape) == (1, 3, 4, 4) and pc.points_list[0].shape[0] == cloud.points_list[0].shape[0]
+
+
+def test_image_recover_slam_values_vs_oracle():
+    """H15 (slam/custom_slam.py:6-35) with PointFusion(odom="gt"): the fused map after three frames -- point count, positions,
+    normals, colours and confidences -- against the oracle's PointFusion chain, and the gradient of a loss on the map reaches
+    the LAST frame's depth only (every earlier frame is detached by image_recover_slam)."""
+    from gradslam import RGBDImages
+    from gradslam.slam import PointFusion
+    from oracle import pointfusion as opf
+    from slam.custom_slam import image_recover_slam
+    from test_gpu_pointfusion_knn import _K, _pose, _scene
+    H, W = 40, 56
+    K = _K(H, W)
+    ds, cs, ps = [], [], []
+    for i in range(3):
+        d, c = _scene(H, W, 30)
+        ds.append(d); cs.append(c); ps.append(_pose(0.3 * i, 0.6 * i, 0.0, (0.012 * i, 0.0, -0.01 * i)))
+    st = opf.empty_state()
+    for d, c, p in zip(ds, cs, ps):
+        st, _ = opf.pointfusion_step(st, c, d, K, p)
+    depth = torch.stack(ds, 0).to(DEV)[None, ..., None].requires_grad_(True)
+    frames = RGBDImages(torch.stack(cs, 0).to(DEV)[None], depth, K.to(DEV)[None, None], torch.stack(ps, 0).to(DEV)[None])
+    cloud = image_recover_slam(frames, PointFusion(odom="gt", device=DEV), DEV)
+    P = cloud.points_list[0]
+    assert P.shape[0] == st["points"].shape[0]
+    torch.testing.assert_close(P.detach().cpu(), st["points"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(cloud.normals_list[0].detach().cpu(), st["normals"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(cloud.colors_list[0].detach().cpu(), st["colors"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(cloud.features_list[0].detach().cpu().reshape(-1), st["ccounts"], rtol=1e-5, atol=1e-6)

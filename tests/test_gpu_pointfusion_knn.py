@@ -93,7 +93,7 @@ def _assert_state(m, st, exact_geometry):
     torch.testing.assert_close(cc, st["ccounts"], rtol=1e-6, atol=0)
 
 
-@pytest.mark.parametrize("H,W", [(24, 32), (60, 80), (120, 160)])
+@pytest.mark.parametrize("H,W", [(24, 32), (60, 80), (120, 160), (480, 640)])
 def test_pointfusion_step_tables_bitexact(H, W):
     """frame 0 into an empty map, then frame 1 (moved camera) against it: all three index tables bit-exact."""
     K = _K(H, W)
@@ -113,7 +113,7 @@ def test_pointfusion_step_tables_bitexact(H, W):
         got = m.table(name).cpu()
         assert got.shape == tab[name].shape, f"{name}: {got.shape[0]} rows vs {tab[name].shape[0]}"
         assert torch.equal(got, tab[name]), f"{name} table differs"
-    assert tab["unique"].shape[0] > 0.3 * H * W            # the case is not trivial
+    assert tab["unique"].shape[0] > (0.3 if H < 480 else 0.05) * H * W     # the case is not trivial (the fixed 2 cm motion is many pixels at 480x640)
     assert torch.equal(maps["Vg"][0].cpu(), tab["maps"]["Vg"])
     _assert_state(m, st1, exact_geometry=False)
 
