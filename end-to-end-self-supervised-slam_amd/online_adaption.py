@@ -31,6 +31,7 @@ if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 
 from depth_estimation.networks import DispResNet_Indoor  # noqa: E402
+from depth_estimation.view_synthesis import BackprojectDepth, Project3D  # noqa: E402
 from e2ehip import conv as e2e_conv  # noqa: E402
 from e2ehip import dist as edist  # noqa: E402
 from e2ehip import ops  # noqa: E402
@@ -38,7 +39,9 @@ from e2ehip.fused import LossGradPlan  # noqa: E402
 from e2ehip.fusionmap import FusionMap  # noqa: E402
 from e2ehip.stepplan import RefineStepPlan  # noqa: E402
 from e2ehip.synthetic import make_sequence  # noqa: E402
-from utils.training_utils import define_optim, define_schedular, torch_poses_to_transforms  # noqa: E402
+from loss.losses import (SSIM, depth_gt_loss, depth_reguralizer, disparity_smoothness_loss, geometric_consistency_loss,  # noqa: E402
+                         min_reprojection_loss, photometric_loss)
+from utils.training_utils import define_optim, define_schedular, sparse_sampling, torch_poses_to_transforms  # noqa: E402
 from utils.yaml_configs import load_yaml  # noqa: E402
 
 
@@ -109,9 +112,10 @@ class SLAM:
         reg = a.LOSS.depth_regularizer_type if a.LOSS.depth_regularizer else None
         self.plan = LossGradPlan(1, self.H, self.W, self.device, a.MODEL.padding_mode, a.LOSS.photometric_mask, reg,
                                  1.0, a.LOSS.depth_regularizer_weight if reg else 0.0)
-        for flag in ("geometric", "smoothness", "supervise_depth", "auto_masking", "min_reprojection"):
-            if getattr(a.LOSS, flag):
-                raise NotImplementedError(f"LOSS.{flag} is off in the reference's recommended configuration and is a next scope row (SURVEY.md 8f N3)")
+        # the off-by-default loss terms go operator by operator (refinement_autograd): the reference's modules of the same names
+        self.backproject_depth = BackprojectDepth(a.OPTIMIZATION.batch_size, self.H, self.W)
+        self.project_3d = Project3D(a.OPTIMIZATION.batch_size, self.H, self.W)
+        self.ssim = SSIM()
 
     def load_model_indoor(self):
         path = os.path.join(os.path.expanduser(self.args.MODEL.load_depth_path), "depth.pth.tar")
@@ -265,6 +269,7 @@ class SLAM:
         use_reg = a.LOSS.depth_regularizer and a.OPTIMIZATION.refinement == "PFT"
         use_3d = a.LOSS.three3d_loss and not self.first_iter
         nsteps = a.OPTIMIZATION.refinement_steps if max_steps is None else min(int(max_steps), a.OPTIMIZATION.refinement_steps)
+        flagged = not self._plan_eligible()
         for refine_step in range(nsteps):
             self.optimizer.zero_grad()
             disp = self.models["depth"](colors[0], 0)[("disp", 0, 0)]                     # (2,1,H,W): pair as one batch
@@ -272,13 +277,17 @@ class SLAM:
             if refine_step == 0 and use_reg:
                 initial = delta.clone()                                                  # 1/disp BEFORE scaling (:284-285)
             d_src, d_tgt = depth[0:1], depth[1:2]
-            self.plan.bind(d_tgt.detach(), d_src.detach(), initial[1:2] if use_reg else None, initial[0:1] if use_reg else None,
-                           src, tgt, K, inv_K, T)
-            if refine_step == 0:                     # the pair's geometry is host data: pass it as kernel arguments
-                self.plan.set_host_geometry(self._K_host, torch.pinverse(self._K_host), transform[0, 1].cpu())
-            loss2, g_tgt, g_src = self.plan.step()
-            g_depth = torch.cat([g_src if use_reg else torch.zeros_like(g_tgt), g_tgt], 0)
-            roots, grads = [depth], [g_depth]
+            if flagged:
+                image_loss, loss2 = self.compute_flagged_losses(disp, depth, initial if use_reg else None, src, tgt, gt, K, inv_K, T)
+                roots, grads = [image_loss], [None]
+            else:
+                self.plan.bind(d_tgt.detach(), d_src.detach(), initial[1:2] if use_reg else None, initial[0:1] if use_reg else None,
+                               src, tgt, K, inv_K, T)
+                if refine_step == 0:                     # the pair's geometry is host data: pass it as kernel arguments
+                    self.plan.set_host_geometry(self._K_host, torch.pinverse(self._K_host), transform[0, 1].cpu())
+                loss2, g_tgt, g_src = self.plan.step()
+                g_depth = torch.cat([g_src if use_reg else torch.zeros_like(g_tgt), g_tgt], 0)
+                roots, grads = [depth], [g_depth]
             l3 = None
             if use_3d:
                 l3 = self.compute_3d_loss(d_tgt, K, poses[:, 1], T)
@@ -291,12 +300,63 @@ class SLAM:
             self.refinement_steps_done += 1
             if a.DEBUG.print_metrics:
                 m = ops.depth_metrics(gt[0, 1], d_tgt.detach(), a.DATA.name == "TUM")
-                total = loss2[0] + (a.LOSS.depth_regularizer_weight * loss2[1] if use_reg else 0.0)
+                total = image_loss.detach() if flagged else loss2[0] + (a.LOSS.depth_regularizer_weight * loss2[1] if use_reg else 0.0)
                 if l3 is not None:
                     total = total + a.LOSS.three3d_loss_weight * l3.detach()
                 rec = torch.cat([total.reshape(1), loss2, ratio.reshape(1), m, (l3.detach() if l3 is not None else torch.zeros((), device=self.device)).reshape(1)]).cpu()
                 self._log_step(rec, refine_step, nsteps)
         self.create_refined_pointcloud(colors, gt, poses, median_gt)
+
+    def compute_flagged_losses(self, disp, depth, initial, src, tgt, gt, K, inv_K, T):
+        """novel_view_synthesis + compute_losses of the reference (online_adaption.py:412-455, :473-532) operator by operator -- each
+        operator a HIP kernel behind the reference's module name -- for the flags its recommended configuration leaves off:
+        LOSS.min_reprojection, auto_masking, geometric, smoothness, supervise_depth.  disp / depth (2,1,H,W): [source, target].
+        Returns (everything but the 3-D term, the two-value (photometric, regulariser) log row).
+
+        LOSS.supervise_depth: the reference reads inputs["sparse_gt_depth", ...] here (:633) without ever filling it (its
+        process_inputs :388-410 has no sparse_sampling call, unlike train_depth.py:535-541) and dies with a KeyError; here the keys
+        are filled the way train_depth.py does, so the flag works."""
+        a = self.args
+        lo = a.LOSS
+        d_src, d_tgt = depth[0:1], depth[1:2]
+        outputs = {}
+        camera_points = self.backproject_depth(d_tgt, inv_K)
+        if lo.geometric:
+            grid, warped_depth, valid = self.project_3d(points=camera_points, K=K, T=T, geometric=True)
+            outputs["warped_depth", -1], outputs["valid_mask", -1] = warped_depth, valid
+            synth = ops.grid_sample(src, grid, padding_mode=a.MODEL.padding_mode, align_corners=True)          # sic (:431-434)
+            outputs["interpolated_depth", -1] = ops.grid_sample(d_src, grid, padding_mode=a.MODEL.padding_mode, align_corners=False)
+        else:
+            grid, valid = self.project_3d(points=camera_points, K=K, T=T, geometric=False)
+            synth = ops.grid_sample(src, grid, padding_mode=a.MODEL.padding_mode, align_corners=False)
+        masked = (lambda x: ops.mask_mul(x, valid)) if lo.photometric_mask else (lambda x: x)
+        masked_tgt = masked(tgt)
+        photometric = photometric_loss(ssim=self.ssim, prediction=masked(synth), target=masked_tgt)        # (1,1,H,W): one source frame
+        if lo.auto_masking:
+            auto = photometric_loss(ssim=self.ssim, prediction=masked(src), target=masked_tgt)
+            if lo.min_reprojection:
+                auto = auto + torch.randn(auto.shape, device=auto.device) * 0.00001                          # "Break tie's" (:498)
+            photometric = torch.cat((auto, photometric), dim=1)
+        # one map: its mean; two: the mean of the per-pixel minimum, gradient to the first minimal map (e2e_min_reprojection_lossgrad)
+        loss = min_reprojection_loss(photometric)
+        photo_value = loss.detach()
+        if lo.geometric:
+            loss = loss + torch.stack([geometric_consistency_loss(outputs, -1, self.device)], dim=0).mean() * lo.geometric_weight
+        if lo.smoothness:
+            loss = loss + disparity_smoothness_loss(disp=ops.mean_normalize(disp[0:1]), img=tgt) * lo.smoothness_weight
+        reg_value = torch.zeros((), device=self.device)
+        if initial is not None:
+            reg = depth_reguralizer(initial_depth=initial[0:1], refined_depth=d_src, loss_func=lo.depth_regularizer_type) \
+                + depth_reguralizer(initial_depth=initial[1:2], refined_depth=d_tgt, loss_func=lo.depth_regularizer_type)
+            loss = loss + reg * lo.depth_regularizer_weight
+            reg_value = reg.detach()
+        if lo.supervise_depth:
+            gt_loss = 0
+            for index, d in enumerate((d_src, d_tgt)):
+                sparse, mask = sparse_sampling(lo.sampling_type, lo.sampling_prob, gt[:, index].permute(0, 3, 1, 2))
+                gt_loss = gt_loss + depth_gt_loss(prediction=d, sparse_groundtruth=sparse, sparse_mask=mask)
+            loss = loss + gt_loss * lo.gt_depth_weight
+        return loss, torch.stack([photo_value, reg_value])
 
     def compute_3d_loss(self, d_tgt, K, pose_tgt, T):
         """End-2-end point supervision (online_adaption.py:457-471 + :638-645): the target frame's local cloud (in world
@@ -359,8 +419,8 @@ def default_config(height=480, width=640, sequence_length=60):
                    refinement_mode=True),
         LOSS=dict(chamfer_distance=False, knn_points=False, auto_masking=False, min_reprojection=False, photometric_mask=True,
                   geometric=False, geometric_weight=0.5, smoothness=False, smoothness_weight=1e-3, depth_regularizer=True,
-                  depth_regularizer_weight=1e-2, depth_regularizer_type="l2", supervise_depth=False, three3d_loss=True,
-                  three3d_loss_weight=1.0),
+                  depth_regularizer_weight=1e-2, depth_regularizer_type="l2", supervise_depth=False, gt_depth_weight=1, sampling_type="random",
+                  sampling_prob=0.05, three3d_loss=True, three3d_loss_weight=1.0),
         OPTIMIZATION=dict(batch_size=1, refinement="PFT", refinement_steps=3, learning_rate=1e-5, optimizer="Adam", schedular="StepLR",
                           schedular_step_size=100, schedular_gamma=0.5),
         DEBUG=dict(print_metrics=True),

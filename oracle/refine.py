@@ -31,6 +31,14 @@ class Config:
     learning_rate = 1e-5
     dist_th, angle_th, sigma = 0.05, 20.0, 0.6
     dataset = "ICL"
+    # off in the recommended configuration (configs/config.yaml); online_adaption.py:486-532
+    min_reprojection = False
+    auto_masking = False
+    geometric = False
+    geometric_weight = 0.5
+    smoothness = False
+    smoothness_weight = 1e-3
+    tie_break_noise = None          # auto-masking + min-reprojection adds randn * 1e-5 (:498); a fixed tensor for tests
 
 
 class Refiner:
@@ -48,7 +56,8 @@ class Refiner:
 
     def predict_depths(self, colors):
         """colors (1,2,H,W,3) -> [depth0, depth1] each (1,1,H,W) = 1/disp (online_adaption.py:281-282)."""
-        return [1 / depthnet.disp_forward(self.sd, colors[:, i]) for i in range(2)]
+        self.disps = [depthnet.disp_forward(self.sd, colors[:, i]) for i in range(2)]
+        return [1 / d for d in self.disps]
 
     def refine_pair(self, colors, gt_depths, poses, K, update_map=True):
         """colors (1,2,H,W,3) in [0,1]; gt_depths (1,2,H,W,1); poses (1,2,4,4); K (1,1,4,4).
@@ -68,9 +77,13 @@ class Refiner:
                 initial = [d.clone().detach() for d in depths]          # pre-scaling (:284-285)
             depths, ratio = warp_loss.median_scale(depths, gt_depths)  # (:292-298)
             self.opt.zero_grad()
-            synth, valid, _ = warp_loss.inverse_warp(depths[1], src, Kc, invK, T, cfg.padding_mode)
-            loss, _ = warp_loss.masked_photometric_mean(synth, tgt, valid, cfg.photometric_mask)
-            rec = {"photometric": loss.item(), "ratio": ratio.item()}
+            if cfg.min_reprojection or cfg.auto_masking or cfg.geometric or cfg.smoothness:
+                loss, photo = self.flagged_image_losses(depths, src, tgt, Kc, invK, T)
+            else:
+                synth, valid, _ = warp_loss.inverse_warp(depths[1], src, Kc, invK, T, cfg.padding_mode)
+                loss, _ = warp_loss.masked_photometric_mean(synth, tgt, valid, cfg.photometric_mask)
+                photo = loss
+            rec = {"photometric": photo.item(), "ratio": ratio.item()}
             if cfg.depth_regularizer:
                 reg = sum(warp_loss.depth_regularizer(initial[i], depths[i], cfg.depth_regularizer_type) for i in range(2))
                 loss = loss + reg * cfg.depth_regularizer_weight
@@ -93,6 +106,38 @@ class Refiner:
             self.update_map(colors, gt_depths, poses, Kc)
             self.first_iter = False
         return records
+
+    def flagged_image_losses(self, depths, src, tgt, Kc, invK, T):
+        """online_adaption.py:412-455 (view synthesis, geometric variant :421-439) + :483-523 with the off-by-default flags: minimum
+        reprojection, auto-masking, geometric consistency, smoothness on the mean-normalised disparity of frame 0."""
+        import torch.nn.functional as F
+        cfg = self.cfg
+        pts = warp_loss.backproject(depths[1], invK)
+        H, W = tgt.shape[2:]
+        if cfg.geometric:
+            grid, wdepth, valid = warp_loss.project(pts, Kc, T, H, W, geometric=True)
+            synth = F.grid_sample(src, grid, padding_mode=cfg.padding_mode, align_corners=True)
+            idepth = F.grid_sample(depths[0], grid, padding_mode=cfg.padding_mode, align_corners=False)
+        else:
+            grid, valid = warp_loss.project(pts, Kc, T, H, W)
+            synth = F.grid_sample(src, grid, padding_mode=cfg.padding_mode, align_corners=False)
+        m = valid if cfg.photometric_mask else 1.0
+        photo = warp_loss.photometric(synth * m, tgt * m)               # one source frame: (1,1,H,W)
+        if not cfg.min_reprojection:
+            photo = photo.mean(1, keepdim=True)
+        if cfg.auto_masking:
+            auto = warp_loss.photometric(src * m, tgt * m)
+            if cfg.min_reprojection:
+                auto = auto + (cfg.tie_break_noise if cfg.tie_break_noise is not None else torch.zeros_like(auto))
+            else:
+                auto = auto.mean(1, keepdim=True)
+            photo = torch.cat((auto, photo), 1)
+        loss = photo_value = photo.mean() if photo.shape[1] == 1 else torch.min(photo, dim=1)[0].mean()
+        if cfg.geometric:
+            loss = loss + torch.stack([warp_loss.geometric_consistency(wdepth, idepth, valid)], 0).mean() * cfg.geometric_weight
+        if cfg.smoothness:
+            loss = loss + warp_loss.normalised_smoothness(self.disps[0], tgt) * cfg.smoothness_weight     # inputs[("disp", 0, 0)] (:603)
+        return loss, photo_value
 
     @torch.no_grad()
     def update_map(self, colors, gt_depths, poses, Kc):

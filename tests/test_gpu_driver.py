@@ -207,3 +207,57 @@ def test_tum_shaped_sequence_vs_oracle_first_keyframe():
     np.testing.assert_allclose(log[:, 3].numpy(), [r["ratio"] for r in recs], rtol=1e-4)
     np.testing.assert_allclose(log[:, 4:11].numpy(), np.array([r["metrics"] for r in recs]), rtol=2e-4, atol=1e-6)   # masked: holes excluded
     assert abs(slam.map.M - ora.map["points"].shape[0]) <= 0.002 * slam.map.M
+
+
+@pytest.mark.parametrize("flags", [("geometric", "smoothness"), ("min_reprojection", "auto_masking"), ("auto_masking",),
+                                   ("geometric", "smoothness", "min_reprojection", "auto_masking")])
+def test_off_by_default_loss_flags_vs_oracle(flags):
+    """online_adaption.py:486-523 with the flags the recommended configuration leaves off: geometric consistency (align_corners=True
+    sampling of the source frame, :431-434), smoothness on the mean-normalised disparity of frame 0, minimum reprojection and
+    auto-masking -- 3 refinement steps of the first keyframe, total loss / photometric part / regulariser / ratio vs the oracle.
+    The reference's random tie-break noise (randn * 1e-5, :498) is switched off on both sides."""
+    import online_adaption as oa
+    from e2ehip.synthetic import make_sequence
+    H, W, L = 64, 96, 2
+    seq = make_sequence(L, H, W, seed=21)
+    sd = depthnet.random_state_dict(0)
+    sd["decoder.decoder.10.conv.weight"] = sd["decoder.decoder.10.conv.weight"] * 40.0       # unique median (see the teacher-forced test)
+    cfg = _cfg(H, W, L)
+    ocfg = refine.Config()
+    for f in flags:
+        setattr(cfg.LOSS, f, True)
+        setattr(ocfg, f, True)
+    cfg.LOSS.geometric_weight, cfg.LOSS.smoothness_weight = ocfg.geometric_weight, ocfg.smoothness_weight
+    real = torch.randn
+    try:
+        torch.randn = lambda *a, **k: torch.zeros(*a, **{kk: v for kk, v in k.items() if kk == "device"})
+        slam = oa.SLAM(cfg, sequence=seq, state_dict=sd)
+        slam.main()
+    finally:
+        torch.randn = real
+    log = torch.stack(slam.log)
+    colors, gt, K, poses = seq
+    recs = refine.Refiner(sd, ocfg).refine_pair(colors, gt, poses, K)
+    np.testing.assert_allclose(log[:, 0].numpy(), [r["loss"] for r in recs], rtol=2e-4)
+    np.testing.assert_allclose(log[:, 1].numpy(), [r["photometric"] for r in recs], rtol=2e-4)
+    np.testing.assert_allclose(log[:, 2].numpy(), [r["reg"] for r in recs], rtol=2e-4, atol=1e-9)
+    np.testing.assert_allclose(log[:, 3].numpy(), [r["ratio"] for r in recs], rtol=1e-4)
+    assert slam.map.M >= H * W
+
+
+def test_sparse_depth_supervision_runs():
+    """LOSS.supervise_depth (random sparse sampling of the ground truth, so no value parity): the term is positive and enters the loss."""
+    import online_adaption as oa
+    from e2ehip.synthetic import make_sequence
+    H, W, L = 64, 96, 2
+    seq = make_sequence(L, H, W, seed=21)
+    sd = depthnet.random_state_dict(0)
+    logs = []
+    for on in (False, True):
+        cfg = _cfg(H, W, L)
+        cfg.LOSS.smoothness = True                       # any flag that selects the operator-by-operator path
+        cfg.LOSS.supervise_depth, cfg.LOSS.sampling_prob = on, 0.05
+        slam = oa.SLAM(cfg, sequence=seq, state_dict=sd)
+        slam.main()
+        logs.append(torch.stack(slam.log)[:, 0])
+    assert torch.isfinite(logs[1]).all() and logs[1][0] > logs[0][0]
