@@ -18,6 +18,7 @@ per refinement step (RCCL over xGMI), and gather their maps at the end.  value =
 --workload warp keeps the round-1 kernel-only workload (BASELINE configs[1]: warp + photometric kernels on one pair).
 """
 import argparse
+import contextlib
 import json
 import os
 import subprocess
@@ -150,7 +151,8 @@ def seq_bench(a, rank, world, dev):
                         scene="corner" if a.odom != "gt" else "plane")
     K = a.steps if a.steps is not None else spk * (L - 1)
     Wm = a.warmup if a.warmup is not None else 6
-    slam = SLAM(cfg, sequence=seq)
+    with contextlib.redirect_stdout(sys.stderr):        # the driver mirrors the reference's start-up prints; stdout carries ONE JSON line
+        slam = SLAM(cfg, sequence=seq)
     slam.set_refinement_mode()
     slam.first_iter = True
     sched = slam.keyframe_schedule()
@@ -194,10 +196,10 @@ def seq_bench(a, rank, world, dev):
     # ---- per-kernel durations of ONE more keyframe, measured live with HIP events on the launch streams --------------
     roof = {}
     if not a.no_roofline:
-        slam.overlap_wgrad = False                      # one stream: a kernel's duration is its own, not a shared GPU's
+        overlap, slam.overlap_wgrad = slam.overlap_wgrad, False     # one stream: a kernel's duration is its own, not a shared GPU's
         with KernelTimer() as kt:
             run_steps(spk)
-        slam.overlap_wgrad = True
+        slam.overlap_wgrad = overlap
         rows = kt.summary()
         conv_ms = sum(rows[n]["ms"] for n in CONV_ENTRY_POINTS if n in rows)
         conv_fl = sum(rows[n]["flops"] for n in CONV_ENTRY_POINTS if n in rows)

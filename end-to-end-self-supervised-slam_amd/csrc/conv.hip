@@ -753,49 +753,204 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
     }
 }
 
+// Backward-weight for the 16-output-channel layers (the two full-resolution decoder convolutions, networks.py:262-266 at level
+// 0): a 32x32x2 tile would spend half of every MFMA on padding rows, so this variant runs v_mfma_f32_16x16x4_f32 -- M = the 16
+// output channels, N = NTL 16-column tiles of (tap, ci) columns held by EVERY wave (NTL x 4 accumulator registers), and the four
+// waves of a workgroup split the pixels of a chunk (K) between them; their accumulators are summed through LDS in wave order at
+// the end.  One workgroup therefore reads a pixel's dZ once for all its columns, and a slab is 16 x 160 floats instead of
+// 32 x 256.  Loader, slab layout and reduction are those of k_wgrad_gemm4.
+template <int NTL, int CB>
+__global__ __launch_bounds__(256) void k_wgrad_gemm16(WgradArgs a) {
+    constexpr int BM = 16, BN = 16 * NTL, BNS = (BN % 32 == 16) ? BN : BN + 16, NT = 256;   // row stride = 16 mod 32 words: the 2 pixel
+    constexpr int A_CNT = CB * (BM / 4), B_CNT = CB * (BN / 4);                            // rows a half-wave reads hit disjoint banks
+    constexpr int A_PER = (A_CNT + NT - 1) / NT, B_PER = (B_CNT + NT - 1) / NT;
+    static_assert(2 * CB * (BM + BNS) >= 3 * NTL * 4 * 64, "tile memory is reused for the cross-wave sum");
+    __shared__ float smem[2 * CB * (BM + BNS)];
+    float (*As)[CB][BM] = reinterpret_cast<float (*)[CB][BM]>(smem);
+    float (*Bs)[CB][BNS] = reinterpret_cast<float (*)[CB][BNS]>(smem + 2 * CB * BM);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nn0 = blockIdx.x * BN;
+    const int64_t P = (int64_t)a.B * a.Ho * a.Wo;
+    const int64_t p0 = (int64_t)blockIdx.z * a.pix_per_slice;
+    const int64_t p1 = (p0 + a.pix_per_slice < P) ? p0 + a.pix_per_slice : P;
+    const int npix = (p1 > p0) ? (int)(p1 - p0) : 0;
+    const int nchunks = (npix + CB - 1) / CB;
+    const int sh = a.up >> 1;
+    const int Hl = a.Hs >> sh, Wl = a.Ws >> sh, C2 = a.Cin - a.C1;
+    const int Kconv = a.KH * a.KW * a.Cin;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, (int)(P * a.Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)((int64_t)a.B * Hl * Wl * a.C1 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0,
+                                                                         (int)(a.src1 ? (int64_t)a.B * a.Hs * a.Ws * C2 * 4 : 0), 0x00020000);
+    int a_kr[A_PER];
+    unsigned a_off[A_PER];
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) {
+        const int idx = tid + j * NT;
+        a_kr[j] = idx / (BM / 4);
+        const int m = (idx - a_kr[j] * (BM / 4)) * 4;
+        a_off[j] = (idx < A_CNT && m < a.Cout) ? (unsigned)(a_kr[j] * a.Cout + m) * 4u : OOB;
+    }
+    int b_kr[B_PER], b_kh[B_PER], b_kw[B_PER], b_ci[B_PER], pb[B_PER], poh[B_PER], pow_[B_PER];
+    bool b_conv[B_PER], b_ones[B_PER], b_src0[B_PER];
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+        const int idx = tid + j * NT;
+        b_kr[j] = idx / (BN / 4);
+        const int col = nn0 + (idx - b_kr[j] * (BN / 4)) * 4;
+        b_conv[j] = idx < B_CNT && col < Kconv;
+        b_ones[j] = idx < B_CNT && a.has_bias && col == Kconv;
+        const int tap = b_conv[j] ? col / a.Cin : 0;
+        b_ci[j] = b_conv[j] ? col - tap * a.Cin : 0;
+        b_src0[j] = b_ci[j] < a.C1;
+        b_kh[j] = tap / a.KW;
+        b_kw[j] = tap - b_kh[j] * a.KW;
+        const int64_t p = p0 + b_kr[j];
+        const int hw = a.Ho * a.Wo;
+        pb[j] = (int)(p / hw);
+        const int r = (int)(p - (int64_t)pb[j] * hw);
+        poh[j] = r / a.Wo;
+        pow_[j] = r - poh[j] * a.Wo;
+    }
+    f4v areg[A_PER], breg[B_PER];
+    int ld_chunk = 0;
+    auto load_chunk = [&]() {
+        const int left = npix - ld_chunk * CB;
+        const int soffz = (int)((p0 + (int64_t)ld_chunk * CB) * a.Cout * 4);
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j)
+            areg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsz, (a_kr[j] < left) ? a_off[j] : OOB, soffz, 0));
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            int ys = poh[j] * a.stride + b_kh[j] - a.pad, xs = pow_[j] * a.stride + b_kw[j] - a.pad;
+            bool ok = b_conv[j] && b_kr[j] < left;
+            if (a.pad_mode == 1) { ys = reflect1(ys, a.Hs); xs = reflect1(xs, a.Ws); }
+            else ok = ok && ys >= 0 && ys < a.Hs && xs >= 0 && xs < a.Ws;
+            const unsigned o0 = (unsigned)(((pb[j] * Hl + (ys >> sh)) * Wl + (xs >> sh)) * a.C1 + b_ci[j]) * 4u;
+            const unsigned o1 = (unsigned)(((pb[j] * a.Hs + ys) * a.Ws + xs) * C2 + (b_ci[j] - a.C1)) * 4u;
+            f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs0, (ok && b_src0[j]) ? o0 : OOB, 0, 0));
+            if (a.src1 != nullptr) {
+                const f4v v1 = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs1, (ok && !b_src0[j]) ? o1 : OOB, 0, 0));
+                v = b_src0[j] ? v : v1;
+            }
+            if (b_ones[j]) v = (f4v){(b_kr[j] < left) ? 1.f : 0.f, 0.f, 0.f, 0.f};
+            breg[j] = v;
+            pow_[j] += CB;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2)
+                if (pow_[j] >= a.Wo) { pow_[j] -= a.Wo; if (++poh[j] == a.Ho) { poh[j] = 0; ++pb[j]; } }
+        }
+        ++ld_chunk;
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            const int idx = tid + j * NT;
+            if (idx >= A_CNT) continue;
+            *(f4v*)&As[buf][a_kr[j]][(idx - a_kr[j] * (BM / 4)) * 4] = areg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int idx = tid + j * NT;
+            if (idx >= B_CNT) continue;
+            *(f4v*)&Bs[buf][b_kr[j]][(idx - b_kr[j] * (BN / 4)) * 4] = breg[j];
+        }
+    };
+    f4v acc[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) acc[t] = (f4v){0.f, 0.f, 0.f, 0.f};
+    if (nchunks > 0) {
+        load_chunk();
+        store_chunk(0);
+    }
+    __syncthreads();
+    const int kq = lane >> 4, l16 = lane & 15;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk();
+#pragma unroll
+        for (int ks = 0; ks < CB / 16; ++ks) {               // this wave's CB / 4 pixel rows of the chunk, 4 per MFMA
+            const int row = wave * (CB / 4) + ks * 4 + kq;
+            const float av = As[buf][row][l16];
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[buf][row][t * 16 + l16], acc[t], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    float* red = smem;                                       // [3 waves][NTL * 4][64]
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[((wave - 1) * NTL * 4 + t * 4 + i) * 64 + lane] = acc[t][i];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    float* slab = a.slabs + (int64_t)blockIdx.z * a.Mpad * a.Npad;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = acc[t][i];
+#pragma unroll
+            for (int w2 = 0; w2 < 3; ++w2) v += red[(w2 * NTL * 4 + t * 4 + i) * 64 + lane];
+            const int m = 4 * kq + i, n = nn0 + t * 16 + l16;            // D[m][n]: lane (kq, l16) holds rows 4 kq .. 4 kq + 3
+            if (n < a.Npad) slab[(int64_t)m * a.Npad + n] = v;
+        }
+}
+
 // sum the S slabs and scatter to dW (Cout,Cin,KH,KW) [accumulating when `accumulate`] and the bias gradient, in ONE launch:
-// a workgroup owns 64 consecutive output elements and spreads the slabs over ZL slab lanes (lane w sums z = w, w + ZL, ...:
-// at most ~8 independent loads per thread, all in flight together); the ZL partial sums are combined through LDS in the fixed
-// order ((p0 + p1) + p2) + ... -- bitwise reproducible.  scale (may be NULL): per-output-channel factor applied to the sum (the
-// folded BatchNorm scale, when the GEMM ran on dA instead of dZ = dA * scale).  (Round 1 ran this as k_slab_fold + k_wgrad_reduce:
-// two launches and a second trip of the folded slabs through HBM for every layer.)
+// a thread owns 4 consecutive columns of one row (16-byte loads, Npad % 4 == 0; a wave reads 1 KB runs of a slab), the ZL waves of
+// a workgroup take the slabs z = w, w + ZL, ... with 4 independent loads in flight, and the ZL partial sums are combined through
+// LDS in the fixed order ((p0 + p1) + p2) + ... -- bitwise reproducible.  scale (may be NULL): per-output-channel factor applied
+// to the sum (the folded BatchNorm scale, when the GEMM ran on dA instead of dZ = dA * scale).  Measured alone on this network's
+// shapes (scratch/reduce_bench.hip): 4-8 us against 8-11 us for the scalar-load form on the many-slab layers, equal on the
+// few-slab ones (17 us at 512x512x3x3, where the 9.4 MB scatter dominates).
 template <int ZL>
 __global__ __launch_bounds__(64 * ZL) void k_wgrad_reduce(const float* __restrict__ slabs, int S, int Mpad, int Npad, int Cout, int Cin,
                                                          int KH, int KW, int has_bias, float* __restrict__ dw, float* __restrict__ dbias,
                                                          int accumulate, const float* __restrict__ scale) {
-    __shared__ float part[ZL][64];
+    __shared__ f4v part[ZL][64];
     const int Kconv = KH * KW * Cin, Ng = Kconv + (has_bias ? 1 : 0);
-    const int64_t total = (int64_t)Cout * Ng;
+    const int nq = (Ng + 3) / 4;
+    const int64_t totalq = (int64_t)Cout * nq;
     const int e = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t slab_elems = (int64_t)Mpad * Npad;
-    for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
-        const int64_t i = base + e;
-        const bool on = i < total;
-        const int m = on ? (int)(i / Ng) : 0, n = on ? (int)(i - (int64_t)m * Ng) : 0;
-        const float* src = slabs + (int64_t)m * Npad + n;
-        float sacc = 0.f;
+    const int64_t slab_q = (int64_t)Mpad * Npad / 4;
+    const f4v zero = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < totalq; base += (int64_t)gridDim.x * 64) {
+        const int64_t q = base + e;
+        const bool on = q < totalq;
+        const int m = on ? (int)(q / nq) : 0, n = on ? (int)(q - (int64_t)m * nq) * 4 : 0;
+        const f4v* src = (const f4v*)(slabs + (int64_t)m * Npad + n);
+        f4v sacc = zero;
         int z = w;
-        for (; z + 7 * ZL < S; z += 8 * ZL) {
-            float v[8];
+        for (; z + 3 * ZL < S; z += 4 * ZL) {
+            f4v v[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = on ? src[(int64_t)(z + ZL * j) * slab_elems] : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = on ? src[(int64_t)(z + ZL * j) * slab_q] : zero;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sacc += v[j];
+            for (int j = 0; j < 4; ++j) sacc += v[j];
         }
-        for (; z < S; z += ZL) sacc += on ? src[(int64_t)z * slab_elems] : 0.f;
+        for (; z < S; z += ZL) sacc += on ? src[(int64_t)z * slab_q] : zero;
         part[w][e] = sacc;
         __syncthreads();
         if (w == 0 && on) {
-            float t = part[0][e];
+            f4v t = part[0][e];
 #pragma unroll
             for (int j = 1; j < ZL; ++j) t += part[j][e];
             if (scale) t *= scale[m];
-            if (n < Kconv) {
-                const int tap = n / Cin, ci = n - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
-                float* d = dw + (((int64_t)m * Cin + ci) * KH + kh) * KW + kw;
-                *d = accumulate ? *d + t : t;
-            } else if (dbias) {
-                dbias[m] = accumulate ? dbias[m] + t : t;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int nn = n + k;
+                if (nn < Kconv) {
+                    const int tap = nn / Cin, ci = nn - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
+                    float* d = dw + (((int64_t)m * Cin + ci) * KH + kh) * KW + kw;
+                    *d = accumulate ? *d + t[k] : t[k];
+                } else if (nn == Kconv && dbias) {
+                    dbias[m] = accumulate ? dbias[m] + t[k] : t[k];
+                }
             }
         }
         __syncthreads();
@@ -983,6 +1138,19 @@ __global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__
         float acc[HC];
 #pragma unroll
         for (int c = 0; c < HC; ++c) acc[c] = 0.f;
+        if (h >= 2 && h < H - 2 && ww >= 2 && ww < W - 2) {
+            // interior (two pixels from every border): no reflected read lands here, the readers are the 9 neighbours
+            // q = p - (kh - 1, kw - 1), each through its own tap
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float g = dz[n - (int64_t)(kh - 1) * W - (kw - 1)];
+                    const float* wt = &sw[(kh * 3 + kw) * HC];
+#pragma unroll
+                    for (int c = 0; c < HC; ++c) acc[c] = fmaf(g, wt[c], acc[c]);
+                }
+        } else
         // output q = (qh,qw) with tap (kh,kw) reads padded position (qh+kh, qw+kw) = pixel reflect(qh+kh-1), reflect(qw+kw-1)
         for (int qh = h - 2; qh <= h + 2; ++qh) {
             if (qh < 0 || qh >= H) continue;
@@ -1381,14 +1549,16 @@ int e2e_head_bwd_act(const float* dz, const float* x, const float* w, float* dx,
 
 // backward-weight decomposition shared by the workspace query and the launch: tile shape, padded GEMM size, pixel slices
 struct WgradPlan { int tm, tn, Mpad, Npad; int64_t S; };
-static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int has_bias) {
+static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int has_bias, bool use16) {
     WgradPlan p;
     const int Ng = KH * KW * Cin + (has_bias ? 1 : 0);
     p.tm = Cout <= 32 ? 32 : 64; p.tn = Cout <= 32 ? 128 : 64;        // 32x128 tiles for the thin layers
+    if (use16) { p.tm = 16; p.tn = 160; }                              // k_wgrad_gemm16 (16x16x4 MFMA tiles)
     p.Mpad = (Cout + p.tm - 1) / p.tm * p.tm; p.Npad = (Ng + p.tn - 1) / p.tn * p.tn;
     const int64_t P = (int64_t)B * Ho * Wo;
     const int64_t tiles = (int64_t)(p.Mpad / p.tm) * (p.Npad / p.tn);
-    int64_t S = (g_wgrad_target + tiles - 1) / tiles;       // pixel slices: ~g_wgrad_target workgroups in total
+    const int target = use16 ? g_wgrad_target * 3 / 4 : g_wgrad_target;     // measured: 768 slices suit the 16-channel kernel (94 vs 110 us)
+    int64_t S = (target + tiles - 1) / tiles;                // pixel slices: ~target workgroups in total
     const int64_t maxS = (P + 255) / 256;                   // at least 256 pixels per slice
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
@@ -1397,8 +1567,13 @@ static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, in
 }
 
 int64_t e2e_conv2d_wgrad_workspace_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int has_bias) {
-    const WgradPlan p = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW, has_bias);
-    return p.S * (int64_t)p.Mpad * p.Npad;
+    const WgradPlan p = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW, has_bias, false);
+    int64_t n = p.S * (int64_t)p.Mpad * p.Npad;
+    if (Cout == 16) {                                                  // the 16-channel kernel is chosen at launch (it needs the lean loader)
+        const WgradPlan q = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW, has_bias, true);
+        if (q.S * (int64_t)q.Mpad * q.Npad > n) n = q.S * (int64_t)q.Mpad * q.Npad;
+    }
+    return n;
 }
 
 static int bwd_weight_impl(const float* dz, const float* src0, const float* src1, int C1, int up, float* dw, float* dbias, float* workspace, int B,
@@ -1412,20 +1587,23 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
     a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cin = Cin; a.C1 = C1; a.up = up; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_mode = pad_mode; a.has_bias = dbias ? 1 : 0;
     a.Ngemm = KH * KW * Cin + a.has_bias;
-    const WgradPlan wp = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW, a.has_bias);
+    const int64_t P = (int64_t)B * Ho * Wo;
+    // lean VEC-4 kernel: 32 pixels per chunk; needs Cout % 4 == 0, 32-bit offsets and image rows of at least 8 pixels
+    const bool lean = vec == 4 && Cout % 4 == 0 && Wo >= 8 && (int64_t)B * Hs * Ws * Cin * 4 < (1ll << 31) && P * Cout * 4 < (1ll << 31);
+    const bool use16 = lean && Cout == 16;
+    const WgradPlan wp = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW, a.has_bias, use16);
     const int tm = wp.tm, tn = wp.tn;
     a.Mpad = wp.Mpad; a.Npad = wp.Npad;
     a.in_sub = in_sub; a.in_mul = in_mul; a.vec = vec;
-    const int64_t P = (int64_t)B * Ho * Wo;
     const int64_t S = wp.S;
-    // lean VEC-4 kernel: 32 pixels per chunk; needs Cout % 4 == 0, 32-bit offsets and image rows of at least 8 pixels
-    const bool lean = vec == 4 && Cout % 4 == 0 && Wo >= 8 && (int64_t)B * Hs * Ws * Cin * 4 < (1ll << 31) && P * Cout * 4 < (1ll << 31);
     const int cbp = lean ? 32 : CBK;
     a.pix_per_slice = ((P + S - 1) / S + cbp - 1) / cbp * cbp;
     const int Sz = (int)((P + a.pix_per_slice - 1) / a.pix_per_slice);
     dim3 g((unsigned)(a.Npad / tn), (unsigned)(a.Mpad / tm), (unsigned)Sz);
     hipStream_t st = (hipStream_t)stream;
-    if (lean) {
+    if (use16) {
+        hipLaunchKernelGGL((k_wgrad_gemm16<10, 32>), g, dim3(256), 0, st, a);
+    } else if (lean) {
         if (tm == 32) hipLaunchKernelGGL((k_wgrad_gemm4<1, 4, 32>), g, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_wgrad_gemm4<2, 2, 32>), g, dim3(256), 0, st, a);
     } else if (tm == 32) {
@@ -1435,11 +1613,12 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
         if (vec == 4) hipLaunchKernelGGL((k_wgrad_gemm<2, 2, 4>), g, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_wgrad_gemm<2, 2, 1>), g, dim3(256), 0, st, a);
     }
-    if (Sz >= 16)
-        hipLaunchKernelGGL((k_wgrad_reduce<16>), dim3(egrid((int64_t)Cout * a.Ngemm * 4)), dim3(1024), 0, st, workspace, Sz, a.Mpad, a.Npad, Cout, Cin,
+    const int64_t quads = (int64_t)Cout * ((a.Ngemm + 3) / 4);
+    if (Sz >= 8)
+        hipLaunchKernelGGL((k_wgrad_reduce<8>), dim3(egrid(quads * 4)), dim3(512), 0, st, workspace, Sz, a.Mpad, a.Npad, Cout, Cin,
                            KH, KW, a.has_bias, dw, dbias, accumulate, out_scale);
     else
-        hipLaunchKernelGGL((k_wgrad_reduce<4>), dim3(egrid((int64_t)Cout * a.Ngemm * 4)), dim3(256), 0, st, workspace, Sz, a.Mpad, a.Npad, Cout, Cin,
+        hipLaunchKernelGGL((k_wgrad_reduce<2>), dim3(egrid(quads * 4)), dim3(128), 0, st, workspace, Sz, a.Mpad, a.Npad, Cout, Cin,
                            KH, KW, a.has_bias, dw, dbias, accumulate, out_scale);
     E2E_LAUNCH_CHECK("e2e_conv2d_bwd_weight");
     return E2E_OK;

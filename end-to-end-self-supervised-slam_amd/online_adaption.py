@@ -60,8 +60,13 @@ class SLAM:
         self.mean_abs = []
         self.log = []
         self.refinement_steps_done = 0
-        # backward-weight chains on a second stream next to backward-data (bench.py's per-kernel timing pass switches it off)
-        self.overlap_wgrad = os.environ.get("E2E_WGRAD_OVERLAP", "1") == "1"
+        # backward-weight chains on a second stream next to backward-data.  Launch plan (captured graphs): OFF by default -- a graph
+        # replay pays 10-16 us for every dependency that crosses queues (profiles/r02_*timeline*), and one convolution GEMM already
+        # fills the GPU: 6.35-6.42 ms/step on one stream against 6.67-6.77 with the side stream.  torch.autograd form (one launch at a
+        # time from the host): ON by default, the second stream hides launch latency there.  E2E_WGRAD_OVERLAP=0/1 forces both.
+        env = os.environ.get("E2E_WGRAD_OVERLAP")
+        self.overlap_wgrad = env == "1"
+        self.overlap_wgrad_autograd = env != "0"
         self.use_graphs = os.environ.get("E2E_STEP_GRAPHS", "1") == "1"
         self.step_plan = None
 
@@ -293,7 +298,7 @@ class SLAM:
                 l3 = self.compute_3d_loss(d_tgt, K, poses[:, 1], T)
                 roots.append(l3 * a.LOSS.three3d_loss_weight)
                 grads.append(None)
-            with e2e_conv.direct_weight_grads(overlap=self.overlap_wgrad):      # weight gradients accumulate straight into FusedAdam's flat bucket
+            with e2e_conv.direct_weight_grads(overlap=self.overlap_wgrad_autograd):     # weight gradients accumulate straight into FusedAdam's flat bucket
                 torch.autograd.backward(roots, grads)
             self._exchange_gradients()
             self.optimizer.step()

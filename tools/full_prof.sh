@@ -8,7 +8,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/fp_$TAG -o full --output-format csv -- 
 f=$(find /tmp/fp_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$f" $OUT/kernel_stats.csv
 t=$(find /tmp/fp_$TAG -name "*kernel_trace.csv" | head -1)
-python3 tools/trace_timeline.py "$t" 0.5 > $OUT/timeline.txt 2>&1
+python3 tools/trace_timeline.py "$t" ${TL_FRAC:-0.3} $TL_DUMP > $OUT/timeline.txt 2>&1
 python3 - "$f" > $OUT/summary.txt <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))

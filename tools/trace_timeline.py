@@ -37,3 +37,27 @@ for s, e, q, n in ev:
     tot[n.split("(")[0][:70]][1] += 1
 for n, (d, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:14]:
     print(f"  {n:70s} {c:6d} calls {d / 1e6:8.2f} ms")
+
+# where the GPU waits: idle gaps (no kernel running on any queue) attributed to the kernel that ended before and the one that
+# started after, largest totals first
+pairs = defaultdict(lambda: [0, 0])
+cur_e, last = None, None
+for s, e, q, n in ev:
+    if cur_e is not None and s > cur_e:
+        key = (last.split("(")[0][:40], n.split("(")[0][:40])
+        pairs[key][0] += s - cur_e
+        pairs[key][1] += 1
+    if cur_e is None or e > cur_e:
+        cur_e, last = e, n
+print("idle gaps by (kernel before -> kernel after):")
+for (a, b), (d, c) in sorted(pairs.items(), key=lambda kv: -kv[1][0])[:25]:
+    print(f"  {a:40s} -> {b:40s} {c:6d} gaps {d / 1e6:8.2f} ms  avg {d / c / 1e3:7.1f} us")
+
+# optional: dump the launches around the LAST occurrence of a kernel (substring match): argv[3] = name, argv[4] = how many before/after
+if len(sys.argv) > 3:
+    name, span_n = sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 30
+    idx = max(i for i, e in enumerate(ev) if name in e[3])
+    t_ref = ev[max(0, idx - span_n)][0]
+    print(f"launches around the last {name}:  start_us end_us dur_us queue name")
+    for s, e, q, n in ev[max(0, idx - span_n): idx + span_n]:
+        print(f"  {(s - t_ref) / 1e3:9.1f} {(e - t_ref) / 1e3:9.1f} {(e - s) / 1e3:7.1f}  q{q}  {n.split('(')[0][:60]}")
