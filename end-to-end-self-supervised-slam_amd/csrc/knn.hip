@@ -88,12 +88,16 @@ __global__ __launch_bounds__(KT) void k_knn1_bwd(const float* __restrict__ g, co
 // Intra-cell order after the scatter depends on atomic arrival order, but min over (distance, index) does not.
 // ---------------------------------------------------------------------------------------------
 #define GRID_MAX_SMALL 128    // cells per axis: reference sets below GRID_BIG_N2 points
-#define GRID_MAX_BIG 256      // ... and above: a map of millions of SURFACE points puts ~300 points in each occupied cell of a
-#define GRID_BIG_N2 1500000   //     128^3 grid (measured: 1.9 ms per query pass at 5 M points); halving h quarters that
+#define GRID_MAX_BIG 256      // ... and above: a map is a SURFACE, so its points crowd the occupied cells (~300 per cell of a 128^3 grid
+#define GRID_BIG_N2 250000    //     at 5 M points); halving h quarters that.  Measured on the benchmark sequence (0.3 - 1.7 M points,
+                              //     307 200 queries, profiles/r02_knn_grid_tuning.txt): 256^3 from 250 k points on + 3 shells in the
+                              //     per-lane pass = 180 + 52 us per query set, against 220 + 198 us with 128^3 up to 1.5 M points and 2
+                              //     shells; the finer grid costs 25 us more per index build
 static inline int grid_max_for(int64_t n2) { return n2 >= GRID_BIG_N2 ? GRID_MAX_BIG : GRID_MAX_SMALL; }
 static inline int64_t grid_cells_cap(int64_t n2) { const int64_t g = grid_max_for(n2); return g * g * g; }
 #define GRID_HMIN 0.01f
-#define GRID_RMAX 2      // shells of the one-query-per-lane pass; whatever it cannot bound goes to the wave-per-query pass
+#define GRID_RMAX 3      // shells of the one-query-per-lane pass; whatever it cannot bound goes to the wave-per-query pass
+                         // (2: 130 + 158 us, 3: 180 + 52 us, 4: 282 + 45 us on the 256^3 grid)
 #define SCAN_BLOCK 1024
 
 struct GridInfo {
