@@ -208,10 +208,18 @@ def seq_bench(a, rank, world, dev):
         all_ms = sum(r["ms"] for r in rows.values())
         if conv_ms > 0:
             tf = conv_fl / (conv_ms * 1e-3) / 1e12
+            # HBM-side bytes per C-ABI convolution call from the committed PMC passes of this same workload (tools/bench_pmc.sh; counters
+            # cannot be read live): bytes of all conv-family kernels per refinement step x steps per keyframe / calls per keyframe
+            traffic, pmc = None, os.path.join(ROOT, "profiles", "r02_bench_pmc_traffic.json")
+            if os.path.isfile(pmc):
+                with open(pmc) as f:
+                    t = json.load(f)
+                traffic = t["conv_gemm_family_bytes_total"] / t["refinement_steps"] * spk / max(conv_calls, 1)
             roof["roofline"] = {
                 "bound": "mfma", "kernel": "depth-network convolution GEMMs (k_conv_gemm forward / backward-data, k_wgrad_gemm* backward-weight incl. their "
                                            "split-K / slab reductions), fp32 v_mfma_f32_32x32x2_f32",
-                "achieved": tf, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFS, "traffic": None,
+                "achieved": tf, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFS, "traffic": traffic,
+                "traffic_note": "bytes per C-ABI convolution call (a call = GEMM + its split-K / slab reduction), profiles/r02_bench_pmc_traffic.json",
                 "launches": conv_calls, "avg_launch_us": 1e3 * conv_ms / max(conv_calls, 1), "algorithmic_gflop_per_keyframe": conv_fl / 1e9,
                 "ms_per_keyframe": conv_ms, "share_of_event_timed_kernel_time": conv_ms / all_ms,
                 "by_entry_point": {n: {"calls": rows[n]["calls"], "ms": round(rows[n]["ms"], 4), "tflops": rows[n]["flops"] / (rows[n]["ms"] * 1e-3) / 1e12}

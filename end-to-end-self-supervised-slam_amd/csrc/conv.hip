@@ -1284,9 +1284,12 @@ static GemmCfg choose_cfg(int64_t rows, int cols, int K, int cb, bool allow_spli
     if (allow_split && cols > 32) {
         const int64_t tiles = ((rows + c.bm - 1) / c.bm) * ((cols + c.bn - 1) / c.bn);
         const int nchunks = (K + cb - 1) / cb;
-        int S = (int)((460 + tiles / 2) / tiles);
-        if (S > 16) S = 16;
-        while (S > 1 && (nchunks / S) * cb < 128) --S;
+        // measured (tools/gemm_tune.py, profiles/r02_gemm_tune_final.txt): ~950 workgroups when the tiles alone give fewer than 500
+        // (336 tiles unsplit: 98 us, 3 slices: 70 us), never below 9 chunks of 32 per slice, never more than 12 slices; 500+ tiles
+        // run unsplit (600 tiles: 42 us, 2 slices: 47 us -- the slab round trip costs more than the fill gains)
+        int S = tiles >= 500 ? 1 : (int)((950 + tiles / 2) / tiles);
+        if (S > 12) S = 12;
+        while (S > 1 && (nchunks / S) * cb < 288) --S;
         c.S = S < 1 ? 1 : S;
     }
     return c;
