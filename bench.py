@@ -166,7 +166,8 @@ def seq_bench(a, rank, world, dev):
                 slam.reset_map()
                 state["i"], state["passes"] = 0, state["passes"] + 1
             k = min(spk, n)
-            slam.refinement(*sched[state["i"]], max_steps=k)
+            nxt = sched[state["i"] + 1] if state["i"] + 1 < len(sched) else None
+            slam.refinement(*sched[state["i"]], max_steps=k, next_pair=nxt)
             slam.first_iter = False
             state["i"] += 1
             n -= k

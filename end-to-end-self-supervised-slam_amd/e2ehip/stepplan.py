@@ -68,7 +68,7 @@ class RefineStepPlan:
         self.net.refresh_layouts()
 
     # ---- per keyframe -----------------------------------------------------------------------------------------------------
-    def set_pair(self, colors_prev, colors_cur, gt_prev, gt_cur, K, T_host, pose_tgt):
+    def set_pair(self, colors_prev, colors_cur, gt_prev, gt_cur, K, T_host, pose_tgt, inv_K=None):
         """Load a keyframe pair into the resident buffers: frames (H,W,3) in [0,1], ground-truth depths (H,W,1), intrinsics K
         (4,4), relative transform T (4,4) = pinv(P_prev) P_cur and the target pose (4,4).  All copies, no kernels of ours but the
         median of the ground-truth depths (online_adaption.py:295: torch.median(gt_depths))."""
@@ -77,7 +77,7 @@ class RefineStepPlan:
         self.gt[0].copy_(gt_prev)
         self.gt[1].copy_(gt_cur)
         self.K[0].copy_(K)
-        self.inv_K[0].copy_(torch.pinverse(K))
+        self.inv_K[0].copy_(torch.pinverse(K) if inv_K is None else inv_K)      # callers with constant intrinsics pass the inverse
         self.T[0].copy_(T_host, non_blocking=True)
         self.pose_tgt[0].copy_(pose_tgt)
         L.call("e2e_median_lower", L.ptr(self.gt), self.gt.numel(), L.ptr(self.median_gt), L.ptr(self.ws_med), L.stream())

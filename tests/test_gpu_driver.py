@@ -172,7 +172,7 @@ def test_launch_plan_equals_autograd_path_and_graph_replay_is_exact():
     # masked mean instead of a mean over gathered rows -> agreement to a few fp32 ulps of each quantity
     np.testing.assert_allclose(log_g.numpy(), log_a.numpy(), rtol=2e-5, atol=1e-7)
     assert map_g.shape == map_a.shape
-    torch.testing.assert_close(map_g, map_a, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(map_g, map_a, rtol=5e-5, atol=5e-6)     # the networks are up to 2 Adam steps of 1e-5 apart (below)
     for k in sd_g:
         if sd_g[k].dtype.is_floating_point:
             torch.testing.assert_close(sd_g[k], sd_a[k], rtol=0, atol=2.5e-5, msg=k)     # <= 2 Adam steps of lr 1e-5 apart where a gradient sign is at noise level
