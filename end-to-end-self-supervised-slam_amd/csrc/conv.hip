@@ -59,6 +59,10 @@ struct ConvArgs {
     // of the producing layer -- and that layer needs no separate activation-backward pass (e2ehip.netplan).
     const float* xin;
     int dact;
+    // transposed form: optional addend in the output's layout, added BEFORE the act' factor: out = (acc + pre) * act'(x) [+ res].
+    // A BasicBlock's input receives conv1's backward-data and the block's residual gradient -- both are gradients with respect to
+    // the same tensor, so the residual one rides here instead of in a separate accumulate pass.
+    const float* pre;
     int64_t bytes0, bytes1, bytesw;   // extents of src0 / src1 / w for the buffer resources (< 2 GB each)
 };
 
@@ -347,6 +351,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         const bool has_res = a.res != nullptr;
         const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)((TRANSPOSED && a.xin) ? a.xin : a.out), 0,
                                                                              (int)((TRANSPOSED && a.xin) ? out_elems * 4 : 0), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc((void*)((TRANSPOSED && a.pre) ? a.pre : a.out), 0,
+                                                                             (int)((TRANSPOSED && a.pre) ? out_elems * 4 : 0), 0x00020000);
 #pragma unroll
         for (int u = 0; u < TM; ++u)
 #pragma unroll
@@ -363,6 +369,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
                 float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[u][t][r], sc, sh);
+                if (TRANSPOSED && a.pre) {                      // a second gradient of the same tensor (residual branch)
+                    float pp[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        pp[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsp, vo[r], ((r & 3) + 8 * (r >> 2)) * a.Ncols * 4, 0));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += pp[r];
+                }
                 if (TRANSPOSED && a.dact) {                     // x (act') of the tensor this gradient belongs to
                     float xx[16];
 #pragma unroll
@@ -419,6 +433,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
                 const unsigned yc = Wc == 1 ? rem : __umulhi(rem, mg_w), xc = rem - yc * (unsigned)Wc;
                 const int64_t orow = ((int64_t)b * a.Hd + 2 * yc + py) * a.Wd + 2 * xc + px;
                 float v = fmaf(acc[u][t][r], sc, sh);
+                if (a.pre) v += a.pre[orow * a.Ncols + col];
                 if (a.dact) v *= act_deriv(a.xin[orow * a.Ncols + col], a.dact);
                 if (a.res) v += a.res[orow * a.Ncols + col];
                 a.out[orow * a.Ncols + col] = apply_act(v, a.act);
@@ -428,12 +443,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
 
 __global__ __launch_bounds__(256) void k_conv_splitk_epilogue(const float* __restrict__ slab, int S, int64_t total, int Ncols,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
-                                                              const float* res, float* out, int act, const float* __restrict__ xin, int dact) {
+                                                              const float* res, float* out, int act, const float* __restrict__ xin, int dact,
+                                                              const float* __restrict__ pre) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         for (int z = 0; z < S; ++z) v += slab[(int64_t)z * total + i];        // fixed order
         const int col = (int)(i % Ncols);
         v = fmaf(v, scale ? scale[col] : 1.f, shift ? shift[col] : 0.f);
+        if (pre) v += pre[i];
         if (dact) v *= act_deriv(xin[i], dact);
         if (res) v += res[i];
         out[i] = apply_act(v, act);
@@ -1346,7 +1363,7 @@ static void launch_gemm(ConvArgs a, int vec, float* workspace, hipStream_t st) {
             dim3 g((unsigned)((Ntot + c.bm - 1) / c.bm), (unsigned)((a.Ncols + c.bn - 1) / c.bn), (unsigned)Sz);
             launch_tile<TR>(a, cb, c, g, st);
             const int64_t total = Ntot * a.Ncols;
-            hipLaunchKernelGGL(k_conv_splitk_epilogue, dim3(egrid(total)), dim3(256), 0, st, workspace, Sz, total, a.Ncols, a.scale, a.shift, a.res, a.out, a.act, a.xin, a.dact);
+            hipLaunchKernelGGL(k_conv_splitk_epilogue, dim3(egrid(total)), dim3(256), 0, st, workspace, Sz, total, a.Ncols, a.scale, a.shift, a.res, a.out, a.act, a.xin, a.dact, a.pre);
             return;
         }
         a.ksplit = 1; a.cps = 0;
@@ -1435,8 +1452,9 @@ int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const f
 }
 
 static int bwd_data_impl(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout, int Ho, int Wo,
-                         int KH, int KW, int stride, int pad, int pad_mode, int accumulate, const float* x_in, int in_act, float* workspace,
-                         void* stream) {
+                         int KH, int KW, int stride, int pad, int pad_mode, int accumulate, const float* x_in, int in_act, const float* pre_add,
+                         float* workspace, void* stream) {
+    E2E_REQUIRE(pre_add == nullptr || pad_mode == 0, E2E_ERR_ARG, "e2e_conv2d_bwd_data: the pre-activation addend takes a zero-padded layer");
     E2E_REQUIRE(in_act == 0 || (x_in && (in_act == ACT_RELU || in_act == ACT_ELU) && pad_mode == 0), E2E_ERR_ARG,
                 "e2e_conv2d_bwd_data: the fused input-activation derivative takes ReLU / ELU, the activation's output and a zero-padded layer");
     E2E_REQUIRE(dz && w_bwd && dxp && B > 0 && Cin > 0 && Cout > 0 && Cout % 16 == 0, E2E_ERR_ARG, "e2e_conv2d_bwd_data: bad argument (Cout %% 16 == 0)");
@@ -1456,7 +1474,7 @@ static int bwd_data_impl(const float* dz, const float* w_bwd, int ld_bwd, float*
         (void)hipMemsetAsync(dxp, 0, (size_t)B * a.Hd * a.Wd * Cin * sizeof(float), (hipStream_t)stream);
     // accumulate: dxp += result -- the epilogue's residual input reads the element it is about to overwrite (same thread)
     if (accumulate) a.res = dxp;
-    a.xin = in_act ? x_in : nullptr; a.dact = in_act;
+    a.xin = in_act ? x_in : nullptr; a.dact = in_act; a.pre = pre_add;
     launch_gemm<true>(a, 4, a.cls ? nullptr : workspace, (hipStream_t)stream);
     E2E_LAUNCH_CHECK("e2e_conv2d_bwd_data");
     return E2E_OK;
@@ -1464,19 +1482,20 @@ static int bwd_data_impl(const float* dz, const float* w_bwd, int ld_bwd, float*
 
 int e2e_conv2d_bwd_data(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout,
                         int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, float* workspace, void* stream) {
-    return bwd_data_impl(dz, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, 0, nullptr, 0, workspace, stream);
+    return bwd_data_impl(dz, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, 0, nullptr, 0, nullptr, workspace, stream);
 }
 
 int e2e_conv2d_bwd_data_acc(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout,
                             int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, int accumulate, float* workspace,
                             void* stream) {
-    return bwd_data_impl(dz, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate, nullptr, 0, workspace, stream);
+    return bwd_data_impl(dz, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate, nullptr, 0, nullptr, workspace, stream);
 }
 
 int e2e_conv2d_bwd_data_fused(const float* da, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout,
                               int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, int accumulate, const float* x_in,
-                              int in_act, float* workspace, void* stream) {
-    return bwd_data_impl(da, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate, x_in, in_act, workspace, stream);
+                              int in_act, const float* pre_add, float* workspace, void* stream) {
+    return bwd_data_impl(da, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate, x_in, in_act, pre_add, workspace,
+                         stream);
 }
 
 int e2e_conv2d_gather_adjoint(const float* dxp, int B, int Hs, int Ws, int Cin, int C1, int up, int padded, float* d_src0,

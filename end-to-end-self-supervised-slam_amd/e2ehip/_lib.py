@@ -97,7 +97,7 @@ SIGNATURES = {
     "e2e_conv2d_act_bwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp],
     "e2e_conv2d_bwd_data": [c_fp, c_fp, c_int, c_fp] + [c_int] * 12 + [c_fp, c_fp],
     "e2e_conv2d_bwd_data_acc": [c_fp, c_fp, c_int, c_fp] + [c_int] * 13 + [c_fp, c_fp],
-    "e2e_conv2d_bwd_data_fused": [c_fp, c_fp, c_int, c_fp] + [c_int] * 13 + [c_fp, c_int, c_fp, c_fp],
+    "e2e_conv2d_bwd_data_fused": [c_fp, c_fp, c_int, c_fp] + [c_int] * 13 + [c_fp, c_int, c_fp, c_fp, c_fp],
     "e2e_conv2d_gather_adjoint_act": [c_fp] + [c_int] * 7 + [c_fp, c_fp, c_int, c_int, c_fp, c_int, c_fp, c_int, c_fp],
     "e2e_conv2d_bwd_weight_scaled": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp] + [c_int] * 13 + [c_f32, c_f32, c_fp],
     "e2e_head_bwd_act": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp],

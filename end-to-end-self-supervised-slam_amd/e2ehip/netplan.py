@@ -96,6 +96,10 @@ class _Conv:
             self.dxp = None if self.direct else torch.empty(B, self.Hs + 2 * self.pp, self.Ws + 2 * self.pp, self.Cin, device=dev, dtype=_f32)
         self.ws_w = torch.empty(lib.e2e_conv2d_wgrad_workspace_floats(B, self.Ho, self.Wo, self.Cin, self.Cout, self.KH, self.KW,
                                                                       1 if bias is not None else 0), device=dev, dtype=_f32)
+        # residual wiring of a BasicBlock (NetPlan.__init__): `res_via` = the block's first convolution, whose backward-data launch
+        # adds this layer's gradient to the block input (pre_add) -- no separate accumulate pass; `res_aliased`: the residual tensor
+        # has no activation and no other consumer (downsample branch), its gradient buffer IS this layer's
+        self.res_via, self.res_aliased, self.pre_from = None, False, None
 
     def layout_row(self):
         return [self.weight.data_ptr(), self.wf.data_ptr(), self.wb.data_ptr() if self.wb is not None else 0, self.Cout, self.Cin, self.KH, self.KW,
@@ -111,13 +115,15 @@ class _Conv:
         s = self
         B, n = s.src0.B, s.out.t.numel()
         g = s.out.g                                 # d loss / d (pre-activation of this layer)
-        if s.res is not None:                       # residual branch: its tensor's pre-activation gradient (+)= g * act_res'(.)
+        if s.res is not None and s.res_via is None and not s.res_aliased:
+            # residual branch: its tensor's pre-activation gradient (+)= g * act_res'(.)
             L.call("e2e_conv2d_act_bwd_acc", L.ptr(g), L.ptr(s.res.t), None, L.ptr(s.res.g), n, s.Cout, s.res.act, 1 if s.res.written else 0, st)
             s.res.written = True
         if s.need_dx:
             if s.direct:
+                pre = s.pre_from.out.g if s.pre_from is not None else None       # the block's residual gradient: same tensor, same act'
                 L.call("e2e_conv2d_bwd_data_fused", L.ptr(g), L.ptr(s.wb), s.ldb, L.ptr(s.src0.g), B, s.Hs, s.Ws, s.Cin, s.Cout, s.Ho, s.Wo, s.KH, s.KW,
-                       s.stride, s.pad, s.pm, 1 if s.src0.written else 0, L.ptr(s.src0.t), s.src0.act, L.ptr(s.ws_b), st)
+                       s.stride, s.pad, s.pm, 1 if s.src0.written else 0, L.ptr(s.src0.t), s.src0.act, L.ptr(pre), L.ptr(s.ws_b), st)
                 s.src0.written = True
             else:
                 L.call("e2e_conv2d_bwd_data", L.ptr(g), L.ptr(s.wb), s.ldb, L.ptr(s.dxp), B, s.Hs, s.Ws, s.Cin, s.Cout, s.Ho, s.Wo, s.KH, s.KW, s.stride,
@@ -235,8 +241,17 @@ class NetPlan:
                 if not isinstance(blk, BasicBlock):
                     raise NotImplementedError("launch plan: BasicBlock encoders (ResNet-18 / 34)")
                 idt = x if blk.downsample is None else conv_bn(x, blk.downsample[0], blk.downsample[1], False)
+                idt_op = self.ops[-1]
                 h = conv_bn(x, blk.conv1, blk.bn1, True)
+                c1 = self.ops[-1]
                 x = conv_bn(h, blk.conv2, blk.bn2, True, residual=idt)
+                c2 = self.ops[-1]
+                if blk.downsample is None:
+                    if c1.direct and c1.need_dx:          # out += identity: d/d(block input) rides in conv1's backward-data epilogue
+                        c2.res_via, c1.pre_from = c1, c2
+                elif isinstance(idt_op, _BNAffine) and idt.act == 0:
+                    idt.g = c2.out.g                       # identity branch without activation and with ONE consumer: share the gradient buffer
+                    c2.res_aliased = True
             feats.append(x)
         self.features = feats
         x = feats[-1]

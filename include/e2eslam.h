@@ -383,11 +383,14 @@ int e2e_conv2d_bwd_data_acc(const float* dz, const float* w_bwd, int ld_bwd, flo
  * buffer: `da` is that gradient of this layer's output (no separate dY * act'(Y) pass; a folded BatchNorm scale is folded into
  * w_bwd by e2e_conv_weight_layouts_batched), and with in_act = 1 (ReLU) / 2 (ELU) the epilogue multiplies the result by
  * act'(.) of the tensor x_in (B,Hs,Ws,Cin) the forward convolution read, so dxp is already the pre-activation gradient of the
- * layer that produced x_in (pad_mode 0 only; reflection-padded layers apply it in e2e_conv2d_gather_adjoint_act). */
+ * layer that produced x_in (pad_mode 0 only; reflection-padded layers apply it in e2e_conv2d_gather_adjoint_act).
+ * pre_add (may be NULL; (B,Hs,Ws,Cin)): a second gradient with respect to the same tensor -- the residual branch of a BasicBlock
+ * (networks.py / torchvision BasicBlock.forward `out += identity`) -- added before the act' factor:
+ * dxp (+)= (dA * W^T + pre_add) * act'(x_in). */
 int e2e_conv2d_bwd_data_fused(const float* da, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs,
                               int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride,
                               int pad, int pad_mode, int accumulate, const float* x_in, int in_act,
-                              float* workspace, void* stream);
+                              const float* pre_add, float* workspace, void* stream);
 /* adjoint of the gather: dxp -> d_src0 (B,Hs/up,Ws/up,C1) [, d_src1 (B,Hs,Ws,Cin-C1)]; every output
  * element sums its reflect-pad copies and its up x up readers in a fixed order (no atomics). */
 int e2e_conv2d_gather_adjoint(const float* dxp, int B, int Hs, int Ws, int Cin, int C1, int up,
