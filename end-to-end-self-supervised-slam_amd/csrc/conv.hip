@@ -457,6 +457,33 @@ __global__ __launch_bounds__(256) void k_conv_splitk_epilogue(const float* __res
     }
 }
 
+// the same on 16-byte quads (Ncols % 4 == 0 and total < 2^31: every split layer of this network)
+__global__ __launch_bounds__(256) void k_conv_splitk_epilogue4(const float* __restrict__ slab, int S, unsigned totalq, int Ncols,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* res, float* out, int act, const float* __restrict__ xin, int dact,
+                                                               const float* __restrict__ pre) {
+    const unsigned colq = (unsigned)Ncols >> 2;
+    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < totalq; q += gridDim.x * 256u) {
+        f4v v = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < S; ++z) v += ((const f4v*)slab)[(int64_t)z * totalq + q];        // fixed order
+        const int col = (int)(q % colq) * 4;
+        const f4v sc = scale ? *(const f4v*)(scale + col) : (f4v){1.f, 1.f, 1.f, 1.f};
+        const f4v sh = shift ? *(const f4v*)(shift + col) : (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaf(v[k], sc[k], sh[k]);
+        if (pre) v += ((const f4v*)pre)[q];
+        if (dact) {
+            const f4v xv = ((const f4v*)xin)[q];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] *= act_deriv(xv[k], dact);
+        }
+        if (res) v += ((const f4v*)res)[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], act);
+        ((f4v*)out)[q] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // backward-weight: dW[m, n] = sum_p dZ[p, m] * X[p, n]   (m = cout, n = (kh,kw,ci) [+ 1 ones-column for the bias],
 // p = output pixel) as a split-K GEMM: grid.z slices of the pixel range write partial slabs, k_wgrad_reduce adds
@@ -1104,6 +1131,54 @@ __global__ __launch_bounds__(256) void k_gather_adjoint(const float* __restrict_
     }
 }
 
+// the same for channel counts that are multiples of 4 (every layer of this network): a thread owns a 16-byte channel quad, indices
+// are 32-bit (the host checks the extents) -- the scalar form spends its time in three 64-bit divisions per float (measured
+// 23 us -> see profiles/r02_*kernel_stats* for an up(0,1)-sized call)
+__global__ __launch_bounds__(256) void k_gather_adjoint4(const float* __restrict__ dxp, int B, int Hs, int Ws, int Cin, int C1, int up,
+                                                         int pp, float* __restrict__ d0, float* __restrict__ d1, int acc0, int acc1,
+                                                         const float* __restrict__ x0, int act0, const float* __restrict__ x1, int act1) {
+    const int Hp = Hs + 2 * pp, Wp = Ws + 2 * pp, C2 = Cin - C1, Hl = Hs / up, Wl = Ws / up;
+    const unsigned q0 = (unsigned)B * Hl * Wl * (C1 >> 2), q1 = (unsigned)B * Hs * Ws * (C2 >> 2);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < q0 + q1; i += gridDim.x * 256u) {
+        const bool first = i < q0;
+        unsigned t = first ? i : i - q0;
+        const unsigned Cq = (unsigned)(first ? C1 : C2) >> 2, Hx = first ? Hl : Hs, Wx = first ? Wl : Ws;
+        const int u = first ? up : 1;
+        const unsigned cq = t % Cq; t /= Cq;
+        const unsigned x = t % Wx; t /= Wx;
+        const unsigned y = t % Hx;
+        const unsigned b = t / Hx;
+        const int cc = (first ? 0 : C1) + (int)cq * 4;
+        f4v s = {0.f, 0.f, 0.f, 0.f};
+        for (int dy = 0; dy < u; ++dy)
+            for (int dx = 0; dx < u; ++dx) {
+                const int fy = (int)y * u + dy, fx = (int)x * u + dx;
+                int ys[3] = {fy + pp, -1, -1}, xs[3] = {fx + pp, -1, -1};
+                if (pp) {
+                    if (fy == 1) ys[1] = 0;
+                    if (fy == Hs - 2) ys[2] = Hp - 1;
+                    if (fx == 1) xs[1] = 0;
+                    if (fx == Ws - 2) xs[2] = Wp - 1;
+                }
+#pragma unroll
+                for (int iy = 0; iy < 3; ++iy)
+#pragma unroll
+                    for (int ix = 0; ix < 3; ++ix)
+                        if (ys[iy] >= 0 && xs[ix] >= 0) s += *(const f4v*)(dxp + (((int64_t)b * Hp + ys[iy]) * Wp + xs[ix]) * Cin + cc);
+            }
+        const int64_t e = (int64_t)(first ? i : i - q0) * 4;
+        const int act = first ? act0 : act1;
+        if (act) {
+            const f4v xv = *(const f4v*)((first ? x0 : x1) + e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] *= act_deriv(xv[k], act);
+        }
+        f4v* d = (f4v*)((first ? d0 : d1) + e);
+        if (first ? acc0 : acc1) s += *d;
+        *d = s;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The 1-channel disparity head (networks.py:271-272,289-290): Conv3x3(reflect) 16 -> 1 + 10*sigmoid+0.01.  One output
 // column cannot fill an MFMA tile; it is a 144-tap dot product per pixel -- HBM-bound VALU kernels.
@@ -1363,7 +1438,11 @@ static void launch_gemm(ConvArgs a, int vec, float* workspace, hipStream_t st) {
             dim3 g((unsigned)((Ntot + c.bm - 1) / c.bm), (unsigned)((a.Ncols + c.bn - 1) / c.bn), (unsigned)Sz);
             launch_tile<TR>(a, cb, c, g, st);
             const int64_t total = Ntot * a.Ncols;
-            hipLaunchKernelGGL(k_conv_splitk_epilogue, dim3(egrid(total)), dim3(256), 0, st, workspace, Sz, total, a.Ncols, a.scale, a.shift, a.res, a.out, a.act, a.xin, a.dact, a.pre);
+            if (a.Ncols % 4 == 0 && total < (1ll << 31))
+                hipLaunchKernelGGL(k_conv_splitk_epilogue4, dim3(egrid(total / 4)), dim3(256), 0, st, workspace, Sz, (unsigned)(total / 4), a.Ncols, a.scale, a.shift,
+                                   a.res, a.out, a.act, a.xin, a.dact, a.pre);
+            else
+                hipLaunchKernelGGL(k_conv_splitk_epilogue, dim3(egrid(total)), dim3(256), 0, st, workspace, Sz, total, a.Ncols, a.scale, a.shift, a.res, a.out, a.act, a.xin, a.dact, a.pre);
             return;
         }
         a.ksplit = 1; a.cps = 0;
@@ -1498,13 +1577,21 @@ int e2e_conv2d_bwd_data_fused(const float* da, const float* w_bwd, int ld_bwd, f
                          stream);
 }
 
+// launch the adjoint of pad + upsample + concat: 16-byte channel quads when the channel split allows, 32-bit indices
+static void launch_gather_adjoint(const float* dxp, int B, int Hs, int Ws, int Cin, int C1, int up, int padded, float* d0, float* d1, int acc0, int acc1,
+                                  const float* x0, int act0, const float* x1, int act1, hipStream_t st) {
+    const int64_t n = (int64_t)B * (Hs / up) * (Ws / up) * C1 + (int64_t)B * Hs * Ws * (Cin - C1);
+    if (Cin % 4 == 0 && C1 % 4 == 0 && n < (1ll << 31))
+        hipLaunchKernelGGL(k_gather_adjoint4, dim3(egrid(n / 4)), dim3(256), 0, st, dxp, B, Hs, Ws, Cin, C1, up, padded ? 1 : 0, d0, d1, acc0, acc1, x0, act0, x1, act1);
+    else
+        hipLaunchKernelGGL(k_gather_adjoint, dim3(egrid(n)), dim3(256), 0, st, dxp, B, Hs, Ws, Cin, C1, up, padded ? 1 : 0, d0, d1, acc0, acc1, x0, act0, x1, act1);
+}
+
 int e2e_conv2d_gather_adjoint(const float* dxp, int B, int Hs, int Ws, int Cin, int C1, int up, int padded, float* d_src0,
                               float* d_src1, int accumulate0, int accumulate1, void* stream) {
     E2E_REQUIRE(dxp && d_src0 && B > 0 && Cin > 0 && C1 > 0 && C1 <= Cin && (C1 == Cin || d_src1) && (up == 1 || up == 2), E2E_ERR_ARG,
                 "e2e_conv2d_gather_adjoint: bad argument");
-    const int64_t n = (int64_t)B * (Hs / up) * (Ws / up) * C1 + (int64_t)B * Hs * Ws * (Cin - C1);
-    hipLaunchKernelGGL(k_gather_adjoint, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, dxp, B, Hs, Ws, Cin, C1, up, padded ? 1 : 0,
-                       d_src0, d_src1, accumulate0, accumulate1, (const float*)nullptr, 0, (const float*)nullptr, 0);
+    launch_gather_adjoint(dxp, B, Hs, Ws, Cin, C1, up, padded, d_src0, d_src1, accumulate0, accumulate1, nullptr, 0, nullptr, 0, (hipStream_t)stream);
     E2E_LAUNCH_CHECK("e2e_conv2d_gather_adjoint");
     return E2E_OK;
 }
@@ -1515,9 +1602,7 @@ int e2e_conv2d_gather_adjoint_act(const float* dxp, int B, int Hs, int Ws, int C
                 "e2e_conv2d_gather_adjoint_act: bad argument");
     E2E_REQUIRE((act0 == 0 || src0) && (act1 == 0 || src1) && act0 >= 0 && act0 <= 2 && act1 >= 0 && act1 <= 2, E2E_ERR_ARG,
                 "e2e_conv2d_gather_adjoint_act: an activation derivative needs the activation's output");
-    const int64_t n = (int64_t)B * (Hs / up) * (Ws / up) * C1 + (int64_t)B * Hs * Ws * (Cin - C1);
-    hipLaunchKernelGGL(k_gather_adjoint, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, dxp, B, Hs, Ws, Cin, C1, up, padded ? 1 : 0,
-                       d_src0, d_src1, accumulate0, accumulate1, src0, act0, src1, act1);
+    launch_gather_adjoint(dxp, B, Hs, Ws, Cin, C1, up, padded, d_src0, d_src1, accumulate0, accumulate1, src0, act0, src1, act1, (hipStream_t)stream);
     E2E_LAUNCH_CHECK("e2e_conv2d_gather_adjoint_act");
     return E2E_OK;
 }
