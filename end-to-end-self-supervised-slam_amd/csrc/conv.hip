@@ -441,6 +441,90 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 convolutions with 16 or 32 input and 16 output channels at (almost) full resolution: the last decoder level
+// (networks.py:262-266: upconv(0,0) 32 -> 16, upconv(0,1) 16 -> 16 behind the nearest x2 upsample) and upconv(0,1)'s backward-data.
+// As implicit GEMMs they are 16 columns wide (half of every 32x32x2 MFMA is padding) and read each input pixel nine times through
+// L2 (33-35 TF/s, 85 us for 2.8 GFLOP).  Here a workgroup stages the input PATCH of a TH x 64 output tile once in LDS, channel-major
+// (upsample, reflection / zero padding resolved while staging), keeps all 9 x CIN x 16 weights in registers as MFMA B operands and
+// runs v_mfma_f32_16x16x4_f32 with M = 16 consecutive output pixels of a row, N = the 16 output channels, K = 4 input channels of
+// one tap: one conflict-free ds_read_b32 per MFMA, no im2col traffic.
+//   domain position sampled by output pixel (y, x) and tap (kh', kw') = (y - org + kh', x - org + kw'); forward: org = 1 (pad);
+//   backward-data on the padded grid: org = 2 and the taps flipped (dXp[q] = sum_t dZ[q - t] Wb[t]).
+// ---------------------------------------------------------------------------------------------------------------------
+struct ThinArgs {
+    const float* src;      // (B, Hsrc, Wsrc, CIN) NHWC; the sampled domain is (Hsrc * UP) x (Wsrc * UP)
+    const float* w;        // [(tap, k)][ldw]: k = input channel, columns = output channels
+    const float* bias;     // per output channel or NULL
+    float* out;            // (B, Hd, Wd, 16)
+    int B, Hsrc, Wsrc, Hd, Wd, ldw, act, org, flip;
+};
+
+template <int CIN, int UP, bool REFLECT, int TH>
+__global__ __launch_bounds__(256) void k_conv3x3_thin(ThinArgs a) {
+    constexpr int TW = 64, PH = TH + 2, PW = TW + 2, PWS = 72, PLANE = PH * PWS, KQ = CIN / 4;
+    static_assert(PLANE % 32 == 16, "the two channel planes a half-wave reads must sit 16 banks apart");
+    __shared__ float patch[CIN * PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, b = blockIdx.z;
+    const int HD = a.Hsrc * UP, WD = a.Wsrc * UP;
+    // ---- weights -> registers: B operand of tap t, channel group j: lane (kq, l16) holds W[t][4 j + kq][l16] ------------------
+    float wreg[9][KQ];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) wreg[t][j] = a.w[(int64_t)((a.flip ? 8 - t : t) * CIN + 4 * j + kq) * a.ldw + l16];
+    // ---- stage the patch: pixel-fastest thread mapping (conflict-free LDS stores), one 16-byte channel quad per load --------
+    const float* sb = a.src + (int64_t)b * a.Hsrc * a.Wsrc * CIN;
+    for (int idx = tid; idx < PH * PW * KQ; idx += 256) {
+        const int pix = idx % (PH * PW), q = idx / (PH * PW);
+        const int py = pix / PW, px = pix - py * PW;
+        int Y = y0 - a.org + py, X = x0 - a.org + px;
+        bool ok = true;
+        if (REFLECT) {                                        // tiles that hang over the image edge read clamped rows (their outputs are not stored)
+            Y = min(max(reflect1(Y, HD), 0), HD - 1);
+            X = min(max(reflect1(X, WD), 0), WD - 1);
+        } else {
+            ok = Y >= 0 && Y < HD && X >= 0 && X < WD;
+        }
+        f4v v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *(const f4v*)(sb + ((int64_t)(Y / UP) * a.Wsrc + (X / UP)) * CIN + q * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) patch[(q * 4 + e) * PLANE + py * PWS + px] = v[e];
+    }
+    __syncthreads();
+    // ---- TH * 4 groups of 16 pixels per tile, TH per wave, two at a time (independent accumulator chains) -----------------------
+    const float bv = a.bias ? a.bias[l16] : 0.f;
+    float* ob = a.out + (int64_t)b * a.Hd * a.Wd * 16;
+#pragma unroll 1
+    for (int g2 = 0; g2 < TH; g2 += 2) {
+        const int g0 = wave * TH + g2, g1 = g0 + 1;
+        const int r0 = g0 >> 2, c0 = (g0 & 3) * 16, r1 = g1 >> 2, c1 = (g1 & 3) * 16;
+        f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* p0 = patch + kq * PLANE + r0 * PWS + c0 + l16;
+        const float* p1 = patch + kq * PLANE + r1 * PWS + c1 + l16;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int off = (t / 3) * PWS + (t % 3);
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p0[4 * j * PLANE + off], wreg[t][j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p1[4 * j * PLANE + off], wreg[t][j], acc1, 0, 0, 0);
+            }
+        }
+        // D[m][n]: lane (kq, l16) holds pixels m = 4 kq + i of the group, channel n = l16
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f4v acc = h ? acc1 : acc0;
+            const int y = y0 + (h ? r1 : r0), xb = x0 + (h ? c1 : c0) + 4 * kq;
+            if (y >= a.Hd) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (xb + i < a.Wd) ob[((int64_t)y * a.Wd + xb + i) * 16 + l16] = apply_act(acc[i] + bv, a.act);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_conv_splitk_epilogue(const float* __restrict__ slab, int S, int64_t total, int Ncols,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* res, float* out, int act, const float* __restrict__ xin, int dact,
@@ -1525,6 +1609,15 @@ int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const f
     a.Hd = (Hs + 2 * pad - KH) / stride + 1; a.Wd = (Ws + 2 * pad - KW) / stride + 1;
     a.Ncols = Cout; a.ldw = ld_fwd; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_mode = pad_mode; a.off = 0; a.act = act;
     a.in_sub = in_sub; a.in_mul = in_mul;
+    // the two 16-output-channel layers at the decoder's last level: patch-in-LDS kernel (k_conv3x3_thin)
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && pad_mode == 1 && Cout == 16 && C1 == Cin && !scale && !residual && ld_fwd >= 16 &&
+        ((Cin == 16 && up == 2) || (Cin == 32 && up == 1))) {
+        ThinArgs t{src0, w_fwd, shift, out, B, Hs / up, Ws / up, Hs, Ws, ld_fwd, act, 1, 0};
+        if (Cin == 16) hipLaunchKernelGGL((k_conv3x3_thin<16, 2, true, 8>), dim3((Ws + 63) / 64, (Hs + 7) / 8, B), dim3(256), 0, (hipStream_t)stream, t);
+        else hipLaunchKernelGGL((k_conv3x3_thin<32, 1, true, 4>), dim3((Ws + 63) / 64, (Hs + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, t);
+        E2E_LAUNCH_CHECK("e2e_conv2d_fwd");
+        return E2E_OK;
+    }
     launch_gemm<false>(a, vec, workspace, (hipStream_t)stream);
     E2E_LAUNCH_CHECK("e2e_conv2d_fwd");
     return E2E_OK;
@@ -1540,6 +1633,13 @@ static int bwd_data_impl(const float* dz, const float* w_bwd, int ld_bwd, float*
     E2E_REQUIRE(ld_bwd % 4 == 0 && ld_bwd >= Cin && (stride == 1 || stride == 2), E2E_ERR_ARG, "e2e_conv2d_bwd_data: bad sizes");
     E2E_REQUIRE((int64_t)B * Ho * Wo * Cout * 4 < (1ll << 31) && (int64_t)KH * KW * Cout * ld_bwd * 4 < (1ll << 31), E2E_ERR_ARG,
                 "e2e_conv2d_bwd_data: operands must stay below 2 GB (32-bit buffer offsets)");
+    // 16 -> 16 channels on the padded grid of a reflection-padded layer (upconv(0,1)): dXp[q] = sum_t dZ[q - t] Wb[t], patch kernel
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && pad_mode == 1 && Cin == 16 && Cout == 16 && !accumulate && !in_act && !pre_add && ld_bwd >= 16) {
+        ThinArgs t{dz, w_bwd, nullptr, dxp, B, Ho, Wo, Hs + 2, Ws + 2, ld_bwd, ACT_NONE, 2, 1};
+        hipLaunchKernelGGL((k_conv3x3_thin<16, 1, false, 8>), dim3((Ws + 2 + 63) / 64, (Hs + 2 + 7) / 8, B), dim3(256), 0, (hipStream_t)stream, t);
+        E2E_LAUNCH_CHECK("e2e_conv2d_bwd_data");
+        return E2E_OK;
+    }
     ConvArgs a{};
     a.src0 = dz; a.src1 = nullptr; a.w = w_bwd; a.out = dxp;
     a.B = B; a.Hs = Ho; a.Ws = Wo; a.Cin = Cout; a.C1 = Cout; a.up = 1;
