@@ -1029,6 +1029,92 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm16(WgradArgs a) {
         }
 }
 
+// Backward-weight of the same thin 3x3 layers (16 output channels, 16 or 32 input channels, reflection pad, optional x2 upsample)
+// from a staged patch: dW[co][(tap, ci)] = sum_p dZ[p][co] X[p + tap][ci].  One workgroup stages the dZ tile (4 x 64 pixels) and the
+// input patch (6 x 66 pixels, 16 channels of the source starting at channel c0) in LDS in their natural NHWC order -- both are
+// conflict-free MFMA operands that way -- and each wave sweeps one tile row: per 4 pixels ONE A read (dZ) feeds 9 MFMAs (one per tap)
+// + 1 for the bias column.  The implicit-GEMM form re-reads dZ for every column tile and every input pixel nine times through L2
+// (k_wgrad_gemm16: 94 us / 55 us for the two layers).  The four waves' accumulators are summed through LDS in wave order, a workgroup
+// covers `tiles_x` consecutive tiles and writes ONE slab [16][npad]; k_wgrad_reduce adds the slabs in order.
+struct ThinWgradArgs {
+    const float* dz;       // (B, Hd, Wd, 16)
+    const float* src;      // (B, Hsrc, Wsrc, Csrc); sampled domain (Hsrc * UP) x (Wsrc * UP) = Hd x Wd
+    float* slabs;          // [S][16][npad]
+    int B, Hsrc, Wsrc, Csrc, Hd, Wd, npad, has_bias, tiles_x, nxg;     // nxg: workgroups along x
+};
+
+template <int UP>
+__global__ __launch_bounds__(256) void k_wgrad3x3_thin(ThinWgradArgs a) {
+    constexpr int TH = 4, TW = 64, PH = TH + 2, PW = TW + 2;
+    __shared__ float smem[PH * PW * 16 + TH * TW * 16];
+    float* patch = smem;                                     // [py][px][ci]
+    float* dzs = smem + PH * PW * 16;                        // [row][x][co]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int nhalf = a.Csrc >> 4;
+    const int b = blockIdx.z / nhalf, c0 = (blockIdx.z % nhalf) * 16;
+    const int y0 = blockIdx.y * TH;
+    const float* sb = a.src + (int64_t)b * a.Hsrc * a.Wsrc * a.Csrc + c0;
+    const float* zb = a.dz + (int64_t)b * a.Hd * a.Wd * 16;
+    f4v acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[t] = (f4v){0.f, 0.f, 0.f, 0.f};
+    const float one = (l16 == 0) ? 1.f : 0.f;                // B operand of the bias column: n = 0 only
+    for (int tx = 0; tx < a.tiles_x; ++tx) {
+        const int x0 = (blockIdx.x * a.tiles_x + tx) * TW;
+        if (x0 >= a.Wd) break;                               // workgroup-uniform
+        __syncthreads();                                     // the previous tile's operands are dead
+        for (int idx = tid; idx < PH * PW * 4; idx += 256) { // patch: 16 channels = 4 quads per pixel, quad-fastest (64-byte runs)
+            const int q = idx & 3, pix = idx >> 2;
+            const int py = pix / PW, px = pix - py * PW;
+            const int Y = min(max(reflect1(y0 - 1 + py, a.Hd), 0), a.Hd - 1), X = min(max(reflect1(x0 - 1 + px, a.Wd), 0), a.Wd - 1);
+            *(f4v*)&patch[pix * 16 + q * 4] = *(const f4v*)(sb + ((int64_t)(Y / UP) * a.Wsrc + (X / UP)) * a.Csrc + q * 4);
+        }
+        for (int idx = tid; idx < TH * TW * 4; idx += 256) { // dZ tile; pixels outside the image contribute zeros
+            const int q = idx & 3, pix = idx >> 2;
+            const int r = pix / TW, x = pix - r * TW;
+            const bool ok = y0 + r < a.Hd && x0 + x < a.Wd;
+            *(f4v*)&dzs[pix * 16 + q * 4] = ok ? *(const f4v*)(zb + ((int64_t)(y0 + r) * a.Wd + x0 + x) * 16 + q * 4) : (f4v){0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        const float* ap = dzs + (wave * TW + kq) * 16 + l16;             // A[m = co][k = pixel]: dZ[row = wave][4 ks + kq][co = l16]
+        const float* bp = patch + (wave * PW + kq) * 16 + l16;           // B[k = pixel][n = ci]: X[row + kh][4 ks + kq + kw][ci = l16]
+#pragma unroll 4
+        for (int ks = 0; ks < TW / 4; ++ks) {
+            const float av = ap[ks * 64];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[((t / 3) * PW + (t % 3)) * 16 + ks * 64], acc[t], 0, 0, 0);
+            acc[9] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, one, acc[9], 0, 0, 0);
+        }
+    }
+    // ---- cross-wave sum (fixed order) and the slab: D[m = co][n]: lane (kq, l16) holds co = 4 kq + i, n = l16 -------------------------
+    __syncthreads();
+    float* red = smem;                                       // [3 waves][10 tiles x 4][64 lanes]: the staged operands are dead
+    static_assert(3 * 40 * 64 <= PH * PW * 16 + TH * TW * 16, "reduction scratch");
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[((wave - 1) * 40 + t * 4 + i) * 64 + lane] = acc[t][i];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const int64_t sid = ((int64_t)b * gridDim.y + blockIdx.y) * a.nxg + blockIdx.x;
+    float* slab = a.slabs + sid * 16 * a.npad;
+    const int kconv = 9 * a.Csrc;
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = acc[t][i];
+#pragma unroll
+            for (int w2 = 0; w2 < 3; ++w2) v += red[(w2 * 40 + t * 4 + i) * 64 + lane];
+            const int co = 4 * kq + i;
+            if (t < 9) slab[co * a.npad + t * a.Csrc + c0 + l16] = v;
+            else if (a.has_bias && c0 == 0 && l16 == 0) slab[co * a.npad + kconv] = v;
+        }
+}
+
 // sum the S slabs and scatter to dW (Cout,Cin,KH,KW) [accumulating when `accumulate`] and the bias gradient, in ONE launch:
 // a thread owns 4 consecutive columns of one row (16-byte loads, Npad % 4 == 0; a wave reads 1 KB runs of a slab), the ZL waves of
 // a workgroup take the slabs z = w, w + ZL, ... with 4 independent loads in flight, and the ZL partial sums are combined through
@@ -1773,12 +1859,32 @@ static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, in
     return p;
 }
 
+// decomposition of k_wgrad3x3_thin: workgroups of `tiles_x` consecutive 4 x 64 tiles, ~1200 of them; one slab per workgroup position
+struct ThinWgradPlan { int tiles_x, nxg, ny, npad; int64_t S; };
+static bool thin_wgrad_ok(int Cin, int Cout, int KH, int KW) { return Cout == 16 && KH == 3 && KW == 3 && (Cin == 16 || Cin == 32); }
+static ThinWgradPlan thin_wgrad_plan(int B, int Ho, int Wo, int Cin, int has_bias) {
+    ThinWgradPlan p;
+    const int txt = (Wo + 63) / 64;
+    p.ny = (Ho + 3) / 4;
+    const int64_t total = (int64_t)B * p.ny * txt * (Cin / 16);
+    p.tiles_x = 1;
+    while (total / p.tiles_x > 1400 && p.tiles_x < txt) ++p.tiles_x;
+    p.nxg = (txt + p.tiles_x - 1) / p.tiles_x;
+    p.S = (int64_t)B * p.ny * p.nxg;
+    p.npad = (9 * Cin + (has_bias ? 1 : 0) + 3) / 4 * 4;
+    return p;
+}
+
 int64_t e2e_conv2d_wgrad_workspace_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int has_bias) {
     const WgradPlan p = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW, has_bias, false);
     int64_t n = p.S * (int64_t)p.Mpad * p.Npad;
     if (Cout == 16) {                                                  // the 16-channel kernel is chosen at launch (it needs the lean loader)
         const WgradPlan q = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW, has_bias, true);
         if (q.S * (int64_t)q.Mpad * q.Npad > n) n = q.S * (int64_t)q.Mpad * q.Npad;
+    }
+    if (thin_wgrad_ok(Cin, Cout, KH, KW)) {
+        const ThinWgradPlan t = thin_wgrad_plan(B, Ho, Wo, Cin, has_bias);
+        if (t.S * 16 * t.npad > n) n = t.S * 16 * t.npad;
     }
     return n;
 }
@@ -1797,6 +1903,20 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
     const int64_t P = (int64_t)B * Ho * Wo;
     // lean VEC-4 kernel: 32 pixels per chunk; needs Cout % 4 == 0, 32-bit offsets and image rows of at least 8 pixels
     const bool lean = vec == 4 && Cout % 4 == 0 && Wo >= 8 && (int64_t)B * Hs * Ws * Cin * 4 < (1ll << 31) && P * Cout * 4 < (1ll << 31);
+    hipStream_t st = (hipStream_t)stream;
+    // the thin 3x3 layers (reflection pad, one source, 16 output channels): patch kernel + the common slab reduction
+    if (lean && thin_wgrad_ok(Cin, Cout, KH, KW) && stride == 1 && pad == 1 && pad_mode == 1 && C1 == Cin && Ho == Hs && Wo == Ws) {
+        const ThinWgradPlan t = thin_wgrad_plan(B, Ho, Wo, Cin, a.has_bias);
+        ThinWgradArgs ta{dz, src0, workspace, B, Hs / up, Ws / up, Cin, Ho, Wo, t.npad, a.has_bias, t.tiles_x, t.nxg};
+        const dim3 tg((unsigned)t.nxg, (unsigned)t.ny, (unsigned)(B * (Cin / 16)));
+        if (up == 2) hipLaunchKernelGGL((k_wgrad3x3_thin<2>), tg, dim3(256), 0, st, ta);
+        else hipLaunchKernelGGL((k_wgrad3x3_thin<1>), tg, dim3(256), 0, st, ta);
+        const int64_t tq = (int64_t)Cout * ((a.Ngemm + 3) / 4);
+        hipLaunchKernelGGL((k_wgrad_reduce<8>), dim3(egrid(tq * 4)), dim3(512), 0, st, workspace, (int)t.S, 16, t.npad, Cout, Cin, KH, KW, a.has_bias, dw, dbias,
+                           accumulate, out_scale);
+        E2E_LAUNCH_CHECK("e2e_conv2d_bwd_weight");
+        return E2E_OK;
+    }
     const bool use16 = lean && Cout == 16;
     const WgradPlan wp = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW, a.has_bias, use16);
     const int tm = wp.tm, tn = wp.tn;
@@ -1807,7 +1927,6 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
     a.pix_per_slice = ((P + S - 1) / S + cbp - 1) / cbp * cbp;
     const int Sz = (int)((P + a.pix_per_slice - 1) / a.pix_per_slice);
     dim3 g((unsigned)(a.Npad / tn), (unsigned)(a.Mpad / tm), (unsigned)Sz);
-    hipStream_t st = (hipStream_t)stream;
     if (use16) {
         hipLaunchKernelGGL((k_wgrad_gemm16<10, 32>), g, dim3(256), 0, st, a);
     } else if (lean) {
