@@ -1400,38 +1400,29 @@ __global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__
         float acc[HC];
 #pragma unroll
         for (int c = 0; c < HC; ++c) acc[c] = 0.f;
-        if (h >= 2 && h < H - 2 && ww >= 2 && ww < W - 2) {
-            // interior (two pixels from every border): no reflected read lands here, the readers are the 9 neighbours
-            // q = p - (kh - 1, kw - 1), each through its own tap
+        // the outputs q that read input pixel p through tap (kh, kw): padded position q + (kh - 1, kw - 1) must map to p.  Along one
+        // axis that is q = p - k + 1 (the direct reader) and, for p one pixel away from a border only, the reader that reaches p through
+        // the reflection (p = 1: padded -1, i.e. q = -k; p = n - 2: padded n, i.e. q = n - k + 1).  At most 2 x 2 readers per tap, and
+        // exactly one for interior pixels -- the first version searched a 5 x 5 neighbourhood for every pixel of a border WAVE.
+        const int ry = (h == 1) ? 0 : ((h == H - 2) ? H + 1 : -100);             // reflected reader: q = ry - kh (invalid when out of range)
+        const int rx = (ww == 1) ? 0 : ((ww == W - 2) ? W + 1 : -100);
+        const float* gz = dz + (int64_t)b * H * W;
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const float g = dz[n - (int64_t)(kh - 1) * W - (kw - 1)];
-                    const float* wt = &sw[(kh * 3 + kw) * HC];
-#pragma unroll
-                    for (int c = 0; c < HC; ++c) acc[c] = fmaf(g, wt[c], acc[c]);
+            for (int kw = 0; kw < 3; ++kw) {
+                const float* wt = &sw[(kh * 3 + kw) * HC];
+                const int qy0 = h - kh + 1, qx0 = ww - kw + 1, qy1 = ry - kh, qx1 = rx - kw;
+                const bool y0 = qy0 >= 0 && qy0 < H, x0 = qx0 >= 0 && qx0 < W, y1 = qy1 >= 0 && qy1 < H, x1 = qx1 >= 0 && qx1 < W;
+                float g = (y0 && x0) ? gz[(int64_t)qy0 * W + qx0] : 0.f;
+                if (y1 | x1) {                                                  // border pixels only (divergence is a handful of lanes per row)
+                    if (y0 && x1) g += gz[(int64_t)qy0 * W + qx1];
+                    if (y1 && x0) g += gz[(int64_t)qy1 * W + qx0];
+                    if (y1 && x1) g += gz[(int64_t)qy1 * W + qx1];
                 }
-        } else
-        // output q = (qh,qw) with tap (kh,kw) reads padded position (qh+kh, qw+kw) = pixel reflect(qh+kh-1), reflect(qw+kw-1)
-        for (int qh = h - 2; qh <= h + 2; ++qh) {
-            if (qh < 0 || qh >= H) continue;
-            for (int qw = ww - 2; qw <= ww + 2; ++qw) {
-                if (qw < 0 || qw >= W) continue;
-                const float g = dz[((int64_t)b * H + qh) * W + qw];
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    if (reflect1(qh + kh - 1, H) != h) continue;
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        if (reflect1(qw + kw - 1, W) != ww) continue;
-                        const float* wt = &sw[(kh * 3 + kw) * HC];
-#pragma unroll
-                        for (int c = 0; c < HC; ++c) acc[c] = fmaf(g, wt[c], acc[c]);
-                    }
-                }
+                for (int c = 0; c < HC; ++c) acc[c] = fmaf(g, wt[c], acc[c]);
             }
-        }
         if (dact) {                                              // -> gradient wrt the pre-activation of the layer that produced x
             const f4v* xi = (const f4v*)(xin + n * HC);
 #pragma unroll
