@@ -1037,27 +1037,31 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm16(WgradArgs a) {
 // (k_wgrad_gemm16: 94 us / 55 us for the two layers).  The four waves' accumulators are summed through LDS in wave order, a workgroup
 // covers `tiles_x` consecutive tiles and writes ONE slab [16][npad]; k_wgrad_reduce adds the slabs in order.
 struct ThinWgradArgs {
-    const float* dz;       // (B, Hd, Wd, 16)
-    const float* src;      // (B, Hsrc, Wsrc, Csrc); sampled domain (Hsrc * UP) x (Wsrc * UP) = Hd x Wd
-    float* slabs;          // [S][16][npad]
-    int B, Hsrc, Wsrc, Csrc, Hd, Wd, npad, has_bias, tiles_x, nxg;     // nxg: workgroups along x
+    const float* dz;       // (B, Hd, Wd, 16 MT)
+    const float* src0;     // (B, Hd / up, Wd / up, C1): the (optionally x2 upsampled) first source
+    const float* src1;     // (B, Hd, Wd, Cin - C1): the skip connection, or NULL
+    float* slabs;          // [S][16 MT][npad]
+    int B, Hd, Wd, Cin, C1, up, npad, has_bias, tiles_x, nxg;          // nxg: workgroups along x
 };
 
-template <int UP>
+template <int MT>
 __global__ __launch_bounds__(256) void k_wgrad3x3_thin(ThinWgradArgs a) {
-    constexpr int TH = 4, TW = 64, PH = TH + 2, PW = TW + 2;
-    __shared__ float smem[PH * PW * 16 + TH * TW * 16];
+    constexpr int TH = 4, TW = 64, PH = TH + 2, PW = TW + 2, CO = 16 * MT, NA = 10 * MT;
+    __shared__ float smem[PH * PW * 16 + TH * TW * CO];
     float* patch = smem;                                     // [py][px][ci]
     float* dzs = smem + PH * PW * 16;                        // [row][x][co]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
-    const int nhalf = a.Csrc >> 4;
-    const int b = blockIdx.z / nhalf, c0 = (blockIdx.z % nhalf) * 16;
+    const int nhalf = a.Cin >> 4, n0 = a.C1 >> 4;
+    const int b = blockIdx.z / nhalf, hf = blockIdx.z % nhalf;
+    const bool first = hf < n0;                              // this workgroup's 16 input channels: of src0 (behind the upsample) or of src1
+    const int sh = first ? (a.up >> 1) : 0, Cs = first ? a.C1 : a.Cin - a.C1, cs0 = (first ? hf : hf - n0) * 16;
+    const int Hs = a.Hd >> sh, Ws = a.Wd >> sh;
     const int y0 = blockIdx.y * TH;
-    const float* sb = a.src + (int64_t)b * a.Hsrc * a.Wsrc * a.Csrc + c0;
-    const float* zb = a.dz + (int64_t)b * a.Hd * a.Wd * 16;
-    f4v acc[10];
+    const float* sb = (first ? a.src0 : a.src1) + (int64_t)b * Hs * Ws * Cs + cs0;
+    const float* zb = a.dz + (int64_t)b * a.Hd * a.Wd * CO;
+    f4v acc[NA];
 #pragma unroll
-    for (int t = 0; t < 10; ++t) acc[t] = (f4v){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NA; ++t) acc[t] = (f4v){0.f, 0.f, 0.f, 0.f};
     const float one = (l16 == 0) ? 1.f : 0.f;                // B operand of the bias column: n = 0 only
     for (int tx = 0; tx < a.tiles_x; ++tx) {
         const int x0 = (blockIdx.x * a.tiles_x + tx) * TW;
@@ -1067,52 +1071,72 @@ __global__ __launch_bounds__(256) void k_wgrad3x3_thin(ThinWgradArgs a) {
             const int q = idx & 3, pix = idx >> 2;
             const int py = pix / PW, px = pix - py * PW;
             const int Y = min(max(reflect1(y0 - 1 + py, a.Hd), 0), a.Hd - 1), X = min(max(reflect1(x0 - 1 + px, a.Wd), 0), a.Wd - 1);
-            *(f4v*)&patch[pix * 16 + q * 4] = *(const f4v*)(sb + ((int64_t)(Y / UP) * a.Wsrc + (X / UP)) * a.Csrc + q * 4);
+            *(f4v*)&patch[pix * 16 + q * 4] = *(const f4v*)(sb + ((int64_t)(Y >> sh) * Ws + (X >> sh)) * Cs + q * 4);
         }
-        for (int idx = tid; idx < TH * TW * 4; idx += 256) { // dZ tile; pixels outside the image contribute zeros
-            const int q = idx & 3, pix = idx >> 2;
+        for (int idx = tid; idx < TH * TW * (CO / 4); idx += 256) {     // dZ tile; pixels outside the image contribute zeros
+            const int q = idx % (CO / 4), pix = idx / (CO / 4);
             const int r = pix / TW, x = pix - r * TW;
             const bool ok = y0 + r < a.Hd && x0 + x < a.Wd;
-            *(f4v*)&dzs[pix * 16 + q * 4] = ok ? *(const f4v*)(zb + ((int64_t)(y0 + r) * a.Wd + x0 + x) * 16 + q * 4) : (f4v){0.f, 0.f, 0.f, 0.f};
+            *(f4v*)&dzs[pix * CO + q * 4] = ok ? *(const f4v*)(zb + ((int64_t)(y0 + r) * a.Wd + x0 + x) * CO + q * 4) : (f4v){0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
-        const float* ap = dzs + (wave * TW + kq) * 16 + l16;             // A[m = co][k = pixel]: dZ[row = wave][4 ks + kq][co = l16]
+        const float* ap = dzs + (wave * TW + kq) * CO + l16;             // A[m = co][k = pixel]: dZ[row = wave][4 ks + kq][co = 16 mt + l16]
         const float* bp = patch + (wave * PW + kq) * 16 + l16;           // B[k = pixel][n = ci]: X[row + kh][4 ks + kq + kw][ci = l16]
-#pragma unroll 4
+#pragma unroll 2
         for (int ks = 0; ks < TW / 4; ++ks) {
-            const float av = ap[ks * 64];
+            float av[MT];
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[((t / 3) * PW + (t % 3)) * 16 + ks * 64], acc[t], 0, 0, 0);
-            acc[9] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, one, acc[9], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) av[mt] = ap[ks * 4 * CO + mt * 16];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float bv = bp[((t / 3) * PW + (t % 3)) * 16 + ks * 64];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt * 10 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv, acc[mt * 10 + t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt * 10 + 9] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], one, acc[mt * 10 + 9], 0, 0, 0);
         }
     }
-    // ---- cross-wave sum (fixed order) and the slab: D[m = co][n]: lane (kq, l16) holds co = 4 kq + i, n = l16 -------------------------
+    // ---- cross-wave sum in a fixed tree ((w0 + w2) + (w1 + w3)) through LDS, then the slab ----------------------------------------
+    float* red = smem;                                       // [2 waves][NA x 4][64 lanes]: the staged operands are dead after the barrier
+    static_assert(2 * NA * 4 * 64 <= PH * PW * 16 + TH * TW * CO, "reduction scratch");
     __syncthreads();
-    float* red = smem;                                       // [3 waves][10 tiles x 4][64 lanes]: the staged operands are dead
-    static_assert(3 * 40 * 64 <= PH * PW * 16 + TH * TW * 16, "reduction scratch");
-    if (wave > 0) {
+    if (wave >= 2) {
+#pragma unroll
+        for (int t = 0; t < NA; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[((wave - 2) * NA * 4 + t * 4 + i) * 64 + lane] = acc[t][i];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int t = 0; t < NA; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[t][i] += red[(wave * NA * 4 + t * 4 + i) * 64 + lane];
+    }
+    __syncthreads();                                         // every wave stays until the last barrier
+    if (wave == 1) {
+#pragma unroll
+        for (int t = 0; t < NA; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[(t * 4 + i) * 64 + lane] = acc[t][i];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int64_t sid = ((int64_t)b * gridDim.y + blockIdx.y) * a.nxg + blockIdx.x;
+    float* slab = a.slabs + sid * CO * a.npad;
+    const int kconv = 9 * a.Cin, cg0 = hf * 16;                  // D[m = co][n]: lane (kq, l16) holds co = 16 mt + 4 kq + i, n = l16
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int t = 0; t < 10; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) red[((wave - 1) * 40 + t * 4 + i) * 64 + lane] = acc[t][i];
-    }
-    __syncthreads();
-    if (wave > 0) return;
-    const int64_t sid = ((int64_t)b * gridDim.y + blockIdx.y) * a.nxg + blockIdx.x;
-    float* slab = a.slabs + sid * 16 * a.npad;
-    const int kconv = 9 * a.Csrc;
-#pragma unroll
-    for (int t = 0; t < 10; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v = acc[t][i];
-#pragma unroll
-            for (int w2 = 0; w2 < 3; ++w2) v += red[(w2 * 40 + t * 4 + i) * 64 + lane];
-            const int co = 4 * kq + i;
-            if (t < 9) slab[co * a.npad + t * a.Csrc + c0 + l16] = v;
-            else if (a.has_bias && c0 == 0 && l16 == 0) slab[co * a.npad + kconv] = v;
-        }
+            for (int i = 0; i < 4; ++i) {
+                const float v = acc[mt * 10 + t][i] + red[((mt * 10 + t) * 4 + i) * 64 + lane];
+                const int co = mt * 16 + 4 * kq + i;
+                if (t < 9) slab[co * a.npad + t * a.Cin + cg0 + l16] = v;
+                else if (a.has_bias && hf == 0 && l16 == 0) slab[co * a.npad + kconv] = v;
+            }
 }
 
 // sum the S slabs and scatter to dW (Cout,Cin,KH,KW) [accumulating when `accumulate`] and the bias gradient, in ONE launch:
@@ -1852,7 +1876,11 @@ static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, in
 
 // decomposition of k_wgrad3x3_thin: workgroups of `tiles_x` consecutive 4 x 64 tiles, ~1200 of them; one slab per workgroup position
 struct ThinWgradPlan { int tiles_x, nxg, ny, npad; int64_t S; };
-static bool thin_wgrad_ok(int Cin, int Cout, int KH, int KW) { return Cout == 16 && KH == 3 && KW == 3 && (Cin == 16 || Cin == 32); }
+// measured against the implicit-GEMM kernels (tools/gemm_tune.py wgrad): upconv(0,1) 16 -> 16: 94 -> 66 us, upconv(0,0) 32 -> 16: 55 -> 45 us,
+// upconv(1,1) 96 -> 32: 174 -> 142 us; upconv(1,0) 64 -> 32 is faster as a GEMM (39 vs 46 us) and stays there
+static bool thin_wgrad_ok(int Cin, int Cout, int KH, int KW) {
+    return KH == 3 && KW == 3 && ((Cout == 16 && (Cin == 16 || Cin == 32)) || (Cout == 32 && Cin == 96));
+}
 static ThinWgradPlan thin_wgrad_plan(int B, int Ho, int Wo, int Cin, int has_bias) {
     ThinWgradPlan p;
     const int txt = (Wo + 63) / 64;
@@ -1875,7 +1903,7 @@ int64_t e2e_conv2d_wgrad_workspace_floats(int B, int Ho, int Wo, int Cin, int Co
     }
     if (thin_wgrad_ok(Cin, Cout, KH, KW)) {
         const ThinWgradPlan t = thin_wgrad_plan(B, Ho, Wo, Cin, has_bias);
-        if (t.S * 16 * t.npad > n) n = t.S * 16 * t.npad;
+        if (t.S * Cout * t.npad > n) n = t.S * Cout * t.npad;
     }
     return n;
 }
@@ -1895,15 +1923,16 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
     // lean VEC-4 kernel: 32 pixels per chunk; needs Cout % 4 == 0, 32-bit offsets and image rows of at least 8 pixels
     const bool lean = vec == 4 && Cout % 4 == 0 && Wo >= 8 && (int64_t)B * Hs * Ws * Cin * 4 < (1ll << 31) && P * Cout * 4 < (1ll << 31);
     hipStream_t st = (hipStream_t)stream;
-    // the thin 3x3 layers (reflection pad, one source, 16 output channels): patch kernel + the common slab reduction
-    if (lean && thin_wgrad_ok(Cin, Cout, KH, KW) && stride == 1 && pad == 1 && pad_mode == 1 && C1 == Cin && Ho == Hs && Wo == Ws) {
+    // the thin 3x3 layers of the decoder's last two levels (reflection pad, 16 / 32 output channels): patch kernel + the common slab reduction
+    if (lean && thin_wgrad_ok(Cin, Cout, KH, KW) && stride == 1 && pad == 1 && pad_mode == 1 && C1 % 16 == 0 && Ho == Hs && Wo == Ws &&
+        (C1 == Cin || src1) && Hs % up == 0 && Ws % up == 0) {
         const ThinWgradPlan t = thin_wgrad_plan(B, Ho, Wo, Cin, a.has_bias);
-        ThinWgradArgs ta{dz, src0, workspace, B, Hs / up, Ws / up, Cin, Ho, Wo, t.npad, a.has_bias, t.tiles_x, t.nxg};
+        ThinWgradArgs ta{dz, src0, src1, workspace, B, Ho, Wo, Cin, C1, up, t.npad, a.has_bias, t.tiles_x, t.nxg};
         const dim3 tg((unsigned)t.nxg, (unsigned)t.ny, (unsigned)(B * (Cin / 16)));
-        if (up == 2) hipLaunchKernelGGL((k_wgrad3x3_thin<2>), tg, dim3(256), 0, st, ta);
+        if (Cout == 32) hipLaunchKernelGGL((k_wgrad3x3_thin<2>), tg, dim3(256), 0, st, ta);
         else hipLaunchKernelGGL((k_wgrad3x3_thin<1>), tg, dim3(256), 0, st, ta);
         const int64_t tq = (int64_t)Cout * ((a.Ngemm + 3) / 4);
-        hipLaunchKernelGGL((k_wgrad_reduce<8>), dim3(egrid(tq * 4)), dim3(512), 0, st, workspace, (int)t.S, 16, t.npad, Cout, Cin, KH, KW, a.has_bias, dw, dbias,
+        hipLaunchKernelGGL((k_wgrad_reduce<8>), dim3(egrid(tq * 4)), dim3(512), 0, st, workspace, (int)t.S, Cout, t.npad, Cout, Cin, KH, KW, a.has_bias, dw, dbias,
                            accumulate, out_scale);
         E2E_LAUNCH_CHECK("e2e_conv2d_bwd_weight");
         return E2E_OK;
