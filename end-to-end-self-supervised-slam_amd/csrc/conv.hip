@@ -525,6 +525,72 @@ __global__ __launch_bounds__(256) void k_conv3x3_thin(ThinArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The RGB stem (networks.py:44-50 via torchvision resnet.conv1): 7x7 / stride 2 / pad 3, 3 -> 64 channels, input normalisation
+// (x - 0.45) / 0.225 and folded BatchNorm + ReLU.  As an implicit GEMM its K = 147 cannot use the 16-byte channel-quad loader
+// (scalar gathers: 97 us for 2.9 GFLOP).  Patch kernel: the normalised, zero-padded input patch of a 4 x 32 output tile (14 x 69
+// pixels x 3 channels, 11 KB) is staged once; every wave owns 16 of the 64 output channels with its 37 x 4 weight fragments in
+// registers and sweeps the tile's 8 groups of 16 pixels: v_mfma_f32_16x16x4_f32, M = 16 output pixels, K = 4 of the 148
+// (kh, kw, ci) taps -- tap k of output pixel (y, x) sits at patch offset (2 y) * ROW + 6 x + k + (k / 21) * (ROW - 21).
+// ---------------------------------------------------------------------------------------------------------------------
+struct StemArgs {
+    const float* src;      // (B, Hs, Ws, 3) in [0, 1]
+    const float* w;        // [(kh, kw, ci)][ldw]
+    const float* scale;    // folded BatchNorm (may be NULL)
+    const float* shift;
+    float* out;            // (B, Hd, Wd, 64)
+    int B, Hs, Ws, Hd, Wd, ldw, act;
+    float in_sub, in_mul;
+};
+
+__global__ __launch_bounds__(256) void k_conv7x7_stem(StemArgs a) {
+    constexpr int TH = 4, TW = 32, PH = 2 * TH + 6, PW = 2 * TW + 5, ROW = 208, NJ = 37;        // ROW >= 3 PW = 207
+    __shared__ float patch[PH * ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, b = blockIdx.z;
+    const int co = 16 * wave + l16;
+    float wreg[NJ];
+    int offk[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int k = 4 * j + kq;
+        wreg[j] = k < 147 ? a.w[(int64_t)k * a.ldw + co] : 0.f;
+        offk[j] = k + (k / 21) * (ROW - 21);
+    }
+    const float* sb = a.src + (int64_t)b * a.Hs * a.Ws * 3;
+    for (int idx = tid; idx < PH * ROW; idx += 256) {
+        const int py = idx / ROW, e = idx - py * ROW;
+        const int Y = 2 * y0 - 3 + py, X = 2 * x0 - 3 + e / 3;
+        const bool ok = e < 3 * PW && Y >= 0 && Y < a.Hs && X >= 0 && X < a.Ws;
+        patch[idx] = ok ? (sb[((int64_t)Y * a.Ws + X) * 3 + (e - (e / 3) * 3)] - a.in_sub) * a.in_mul : 0.f;     // zero padding of the NORMALISED image
+    }
+    __syncthreads();
+    const float sc = a.scale ? a.scale[co] : 1.f, sh = a.shift ? a.shift[co] : 0.f;
+    float* ob = a.out + (int64_t)b * a.Hd * a.Wd * 64;
+#pragma unroll 1
+    for (int g = 0; g < 2 * TH; g += 2) {                    // two groups (the two halves of a tile row) per pass: independent chains
+        const int r = g >> 1;
+        const float* p0 = patch + 2 * r * ROW + 6 * l16;
+        const float* p1 = p0 + 6 * 16;
+        f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p0[offk[j]], wreg[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p1[offk[j]], wreg[j], acc1, 0, 0, 0);
+        }
+        const int y = y0 + r;
+        if (y >= a.Hd) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f4v acc = h ? acc1 : acc0;
+            const int xb = x0 + 16 * h + 4 * kq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (xb + i < a.Wd) ob[((int64_t)y * a.Wd + xb + i) * 64 + co] = apply_act(fmaf(acc[i], sc, sh), a.act);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_conv_splitk_epilogue(const float* __restrict__ slab, int S, int64_t total, int Ncols,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* res, float* out, int act, const float* __restrict__ xin, int dact,
@@ -1710,6 +1776,13 @@ int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const f
     a.Hd = (Hs + 2 * pad - KH) / stride + 1; a.Wd = (Ws + 2 * pad - KW) / stride + 1;
     a.Ncols = Cout; a.ldw = ld_fwd; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_mode = pad_mode; a.off = 0; a.act = act;
     a.in_sub = in_sub; a.in_mul = in_mul;
+    // the RGB stem: patch kernel
+    if (KH == 7 && KW == 7 && stride == 2 && pad == 3 && pad_mode == 0 && Cin == 3 && Cout == 64 && C1 == Cin && up == 1 && !residual && ld_fwd >= 64) {
+        StemArgs t{src0, w_fwd, scale, shift, out, B, Hs, Ws, a.Hd, a.Wd, ld_fwd, act, in_sub, in_mul};
+        hipLaunchKernelGGL(k_conv7x7_stem, dim3((a.Wd + 31) / 32, (a.Hd + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, t);
+        E2E_LAUNCH_CHECK("e2e_conv2d_fwd");
+        return E2E_OK;
+    }
     // the two 16-output-channel layers at the decoder's last level: patch-in-LDS kernel (k_conv3x3_thin)
     if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && pad_mode == 1 && Cout == 16 && C1 == Cin && !scale && !residual && ld_fwd >= 16 &&
         ((Cin == 16 && up == 2) || (Cin == 32 && up == 1))) {

@@ -23,7 +23,7 @@ def load(d, counter):
                 acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     return acc
 F, W = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-WIDE = ("k_conv_gemm", "k_wgrad_gemm", "k_wgrad_reduce", "k_adam", "k_weight_layouts", "k_gather_adjoint", "k_act_bwd", "k_maxpool", "k_head", "k_conv_splitk")
+WIDE = ("k_conv_gemm", "k_conv3x3_thin", "k_wgrad3x3_thin", "k_conv7x7", "k_wgrad7x7", "k_wgrad_gemm", "k_wgrad_reduce", "k_adam", "k_weight_layouts", "k_gather_adjoint", "k_act_bwd", "k_maxpool", "k_head", "k_conv_splitk")
 rows = []
 for k in sorted(set(F) | set(W)):
     f = sum(F.get(k, [0])) / max(len(F.get(k, [])), 1) * 1024
@@ -34,7 +34,7 @@ rows.sort(key=lambda r: -(r[3] + r[4]) * r[1])
 print(f"{'kernel':70s} {'launches':>8s} {'FETCH raw MB':>13s} {'FETCH corr MB':>14s} {'WRITE MB':>9s}   (per launch)")
 for k, n, f, fc, w in rows[:40]:
     print(f"{k[:70]:70s} {n:8d} {f / 1e6:13.2f} {fc / 1e6:14.2f} {w / 1e6:9.2f}")
-conv = [r for r in rows if "k_conv_gemm" in r[0] or "k_wgrad_gemm" in r[0] or "k_wgrad_reduce" in r[0] or "k_conv_splitk" in r[0]]
+conv = [r for r in rows if "k_conv_gemm" in r[0] or "_thin" in r[0] or "7x7" in r[0] or "k_wgrad_gemm" in r[0] or "k_wgrad_reduce" in r[0] or "k_conv_splitk" in r[0]]
 n = sum(r[1] for r in conv)
 tot = sum((r[3] + r[4]) * r[1] for r in conv)
 print(json.dumps({"refinement_steps": 12, "conv_gemm_family_kernel_launches": n, "conv_gemm_family_bytes_total": tot, "conv_gemm_family_bytes_per_kernel_launch": tot / max(n, 1)}))
