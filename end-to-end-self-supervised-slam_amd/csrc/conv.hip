@@ -1205,6 +1205,73 @@ __global__ __launch_bounds__(256) void k_wgrad3x3_thin(ThinWgradArgs a) {
             }
 }
 
+// Backward-weight of the RGB stem from the same staged patch: dW[co][k] = sum_p dZ[p][co] * patch(p, k), k = (kh, kw, ci) < 147.
+// Every wave owns 16 output channels (M) and all ten 16-column tiles of k (N, 160 >= 148) -- no cross-wave sum; K = the tile's pixels,
+// 4 per MFMA: one A read (dZ) feeds ten MFMAs.  A workgroup sweeps `tiles_x` tiles and writes one slab [64][148].
+struct StemWgradArgs {
+    const float* dz;       // (B, Hd, Wd, 64)
+    const float* src;      // (B, Hs, Ws, 3)
+    float* slabs;          // [S][64][148]
+    int B, Hs, Ws, Hd, Wd, tiles_x, nxg;
+    float in_sub, in_mul;
+};
+
+__global__ __launch_bounds__(256) void k_wgrad7x7_stem(StemWgradArgs a) {
+    constexpr int TH = 4, TW = 32, PH = 2 * TH + 6, PW = 2 * TW + 5, ROW = 208, NPAD = 148;
+    __shared__ float patch[PH * ROW];
+    __shared__ float dzs[TH * TW * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int y0 = blockIdx.y * TH, b = blockIdx.z;
+    int offn[10];
+#pragma unroll
+    for (int nt = 0; nt < 10; ++nt) {
+        const int k = 16 * nt + l16;                         // columns 147 .. 159 read valid patch cells and are never stored
+        offn[nt] = k + (k / 21) * (ROW - 21) + 6 * kq;       // + this lane's pixel of the MFMA's 4
+    }
+    f4v acc[10];
+#pragma unroll
+    for (int nt = 0; nt < 10; ++nt) acc[nt] = (f4v){0.f, 0.f, 0.f, 0.f};
+    const float* sb = a.src + (int64_t)b * a.Hs * a.Ws * 3;
+    const float* zb = a.dz + (int64_t)b * a.Hd * a.Wd * 64;
+    for (int tx = 0; tx < a.tiles_x; ++tx) {
+        const int x0 = (blockIdx.x * a.tiles_x + tx) * TW;
+        if (x0 >= a.Wd) break;
+        __syncthreads();
+        for (int idx = tid; idx < PH * ROW; idx += 256) {
+            const int py = idx / ROW, e = idx - py * ROW;
+            const int Y = 2 * y0 - 3 + py, X = 2 * x0 - 3 + e / 3;
+            const bool ok = e < 3 * PW && Y >= 0 && Y < a.Hs && X >= 0 && X < a.Ws;
+            patch[idx] = ok ? (sb[((int64_t)Y * a.Ws + X) * 3 + (e - (e / 3) * 3)] - a.in_sub) * a.in_mul : 0.f;
+        }
+        for (int idx = tid; idx < TH * TW * 16; idx += 256) {
+            const int q = idx & 15, pix = idx >> 4;
+            const int r = pix / TW, x = pix - r * TW;
+            const bool ok = y0 + r < a.Hd && x0 + x < a.Wd;
+            *(f4v*)&dzs[pix * 64 + q * 4] = ok ? *(const f4v*)(zb + ((int64_t)(y0 + r) * a.Wd + x0 + x) * 64 + q * 4) : (f4v){0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < TH; ++r) {
+            const float* ap = dzs + (r * TW + kq) * 64 + 16 * wave + l16;        // A[m = co][k = pixel 4 ks + kq]
+            const float* bp = patch + 2 * r * ROW;                               // B[k = pixel][n]: patch(pixel, column 16 nt + l16)
+#pragma unroll 2
+            for (int ks = 0; ks < TW / 4; ++ks) {
+                const float av = ap[ks * 256];
+#pragma unroll
+                for (int nt = 0; nt < 10; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[offn[nt] + ks * 24], acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    float* slab = a.slabs + (((int64_t)b * gridDim.y + blockIdx.y) * a.nxg + blockIdx.x) * 64 * NPAD;
+#pragma unroll
+    for (int nt = 0; nt < 10; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = 16 * nt + l16;
+            if (n < 147) slab[(16 * wave + 4 * kq + i) * NPAD + n] = acc[nt][i];
+        }
+}
+
 // sum the S slabs and scatter to dW (Cout,Cin,KH,KW) [accumulating when `accumulate`] and the bias gradient, in ONE launch:
 // a thread owns 4 consecutive columns of one row (16-byte loads, Npad % 4 == 0; a wave reads 1 KB runs of a slab), the ZL waves of
 // a workgroup take the slabs z = w, w + ZL, ... with 4 independent loads in flight, and the ZL partial sums are combined through
@@ -1978,6 +2045,10 @@ int64_t e2e_conv2d_wgrad_workspace_floats(int B, int Ho, int Wo, int Cin, int Co
         const ThinWgradPlan t = thin_wgrad_plan(B, Ho, Wo, Cin, has_bias);
         if (t.S * Cout * t.npad > n) n = t.S * Cout * t.npad;
     }
+    if (KH == 7 && KW == 7 && Cin == 3 && Cout == 64) {                 // k_wgrad7x7_stem: one slab [64][148] per pair of 4 x 32 tiles
+        const int64_t S = (int64_t)B * ((Ho + 3) / 4) * (((Wo + 31) / 32 + 1) / 2);
+        if (S * 64 * 148 > n) n = S * 64 * 148;
+    }
     return n;
 }
 
@@ -1996,6 +2067,17 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
     // lean VEC-4 kernel: 32 pixels per chunk; needs Cout % 4 == 0, 32-bit offsets and image rows of at least 8 pixels
     const bool lean = vec == 4 && Cout % 4 == 0 && Wo >= 8 && (int64_t)B * Hs * Ws * Cin * 4 < (1ll << 31) && P * Cout * 4 < (1ll << 31);
     hipStream_t st = (hipStream_t)stream;
+    // the RGB stem: patch kernel + the common slab reduction
+    if (KH == 7 && KW == 7 && stride == 2 && pad == 3 && pad_mode == 0 && Cin == 3 && Cout == 64 && C1 == Cin && up == 1 && !dbias &&
+        Ho == (Hs + 6 - 7) / 2 + 1 && Wo == (Ws + 6 - 7) / 2 + 1) {
+        const int nxg = ((Wo + 31) / 32 + 1) / 2, ny = (Ho + 3) / 4;
+        StemWgradArgs ta{dz, src0, workspace, B, Hs, Ws, Ho, Wo, 2, nxg, in_sub, in_mul};
+        hipLaunchKernelGGL(k_wgrad7x7_stem, dim3(nxg, ny, B), dim3(256), 0, st, ta);
+        hipLaunchKernelGGL((k_wgrad_reduce<8>), dim3(egrid((int64_t)64 * 37 * 4)), dim3(512), 0, st, workspace, B * ny * nxg, 64, 148, 64, 3, 7, 7, 0, dw, dbias,
+                           accumulate, out_scale);
+        E2E_LAUNCH_CHECK("e2e_conv2d_bwd_weight");
+        return E2E_OK;
+    }
     // the thin 3x3 layers of the decoder's last two levels (reflection pad, 16 / 32 output channels): patch kernel + the common slab reduction
     if (lean && thin_wgrad_ok(Cin, Cout, KH, KW) && stride == 1 && pad == 1 && pad_mode == 1 && C1 % 16 == 0 && Ho == Hs && Wo == Ws &&
         (C1 == Cin || src1) && Hs % up == 0 && Ws % up == 0) {
