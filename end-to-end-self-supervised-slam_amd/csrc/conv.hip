@@ -63,6 +63,7 @@ struct ConvArgs {
     // A BasicBlock's input receives conv1's backward-data and the block's residual gradient -- both are gradients with respect to
     // the same tensor, so the residual one rides here instead of in a separate accumulate pass.
     const float* pre;
+    int64_t cls_rows;                 // class form with per-tap slices: rows of one (slice, class) slab = B * ceil(Hd/2) * ceil(Wd/2)
     int64_t bytes0, bytes1, bytesw;   // extents of src0 / src1 / w for the buffer resources (< 2 GB each)
 };
 
@@ -141,6 +142,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     const int nchunks_all = (K + CB - 1) / CB;
     const int cbeg = (a.ksplit > 1) ? blockIdx.z * a.cps : 0;
     const int cend = (a.ksplit > 1) ? min(nchunks_all, cbeg + a.cps) : nchunks_all;
+    if (CLS && a.ksplit > 1 && cbeg >= nchunks_all) return;         // class form split by TAP: this class has fewer taps than slices (the
+                                                                    // class epilogue only adds the slices that exist)
 
     // ---- per-thread A slots: slot j is element tid + j*NT of the tile -----------------------------------------------
     //   VEC == 4: element e -> row e / KQ, k-quad e % KQ (the quad is the same for all slots since NT % KQ == 0)
@@ -322,7 +325,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     // none of it overlapped with MFMA work: ~30 % of the kernel's cycles on the 64x64 layers.)
     const int64_t out_elems = (int64_t)a.B * a.Hd * a.Wd * a.Ncols;
     if (a.ksplit > 1) {                                      // raw partial sums; the scale / shift / activation run after the reduction
-        const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.slab + (int64_t)blockIdx.z * Ntot * a.Ncols), 0,
+        // plain form: slab z = [Ntot][Ncols]; class form: slab (z, class) = [cls_rows][Ncols] rows of the class lattice
+        const int64_t slab_id = CLS ? ((int64_t)blockIdx.z * 4 + (py * 2 + px)) * a.cls_rows : (int64_t)blockIdx.z * Ntot;
+        const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.slab + slab_id * a.Ncols), 0,
                                                                              (int)(Ntot * a.Ncols * 4), 0x00020000);
 #pragma unroll
         for (int u = 0; u < TM; ++u)
@@ -604,6 +609,36 @@ __global__ __launch_bounds__(256) void k_conv_splitk_epilogue(const float* __res
         if (dact) v *= act_deriv(xin[i], dact);
         if (res) v += res[i];
         out[i] = apply_act(v, act);
+    }
+}
+
+// class form (stride-2 backward-data) split by tap: output pixel (b, y, x) belongs to class (y & 1, x & 1), its partial sums are row
+// (b, y >> 1, x >> 1) of that class's slabs, one per tap of the class, added in tap order
+__global__ __launch_bounds__(256) void k_conv_splitk_epilogue_cls(const float* __restrict__ slab, int64_t cls_rows, int B, int Hd, int Wd, int Ncols,
+                                                                  int KH, int KW, int off, const float* res, float* out, const float* __restrict__ xin,
+                                                                  int dact, const float* __restrict__ pre) {
+    const unsigned colq = (unsigned)Ncols >> 2, totalq = (unsigned)B * Hd * Wd * colq;
+    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < totalq; q += gridDim.x * 256u) {
+        unsigned t = q;
+        const unsigned cq = t % colq; t /= colq;
+        const unsigned x = t % Wd; t /= Wd;
+        const unsigned y = t % Hd;
+        const unsigned b = t / Hd;
+        const int py = y & 1, px = x & 1;
+        const int kh0 = (py + off) & 1, kw0 = (px + off) & 1;
+        const int ntap = ((KH - kh0 + 1) / 2) * ((KW - kw0 + 1) / 2);
+        const int Hc = (Hd - py + 1) / 2, Wc = (Wd - px + 1) / 2;
+        const int64_t row = ((int64_t)b * Hc + (y >> 1)) * Wc + (x >> 1);
+        f4v v = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < ntap; ++z) v += *(const f4v*)(slab + (((int64_t)z * 4 + (py * 2 + px)) * cls_rows + row) * Ncols + cq * 4);
+        if (pre) v += ((const f4v*)pre)[q];
+        if (dact) {
+            const f4v xv = ((const f4v*)xin)[q];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] *= act_deriv(xv[k], dact);
+        }
+        if (res) v += ((const f4v*)res)[q];
+        ((f4v*)out)[q] = v;
     }
 }
 
@@ -1742,6 +1777,20 @@ static void launch_gemm(ConvArgs a, int vec, float* workspace, hipStream_t st) {
         const int64_t Nc = (int64_t)a.B * ((a.Hd + 1) / 2) * ((a.Wd + 1) / 2);
         GemmCfg c = choose_cfg(Nc * 4, a.Ncols, (K * 9 / 16 + cb - 1) / cb * cb, cb, false);
         if (c.bm == 128 && c.bn == 128) c.bn = 64;
+        // The classes of a 3x3 kernel carry 4, 2, 2 and 1 taps: with so few workgroups the launch lasts as long as a 4-tap one
+        // (l4.0.conv1: 57 us against 26 us for the forward).  Slice every class by TAP: equal work per workgroup, partial sums in
+        // per-(tap, class) slabs, added in tap order by the class epilogue.
+        const int64_t total = Ntot * a.Ncols;
+        const int64_t cls_wgs = 4 * ((Nc + c.bm - 1) / c.bm) * ((a.Ncols + c.bn - 1) / c.bn);     // measured: 304 workgroups 49.7 -> 38.6 us, 160: 57.6 -> 35.1, 600: 39 -> 40
+        if (workspace && cls_wgs < 500 && a.KH == 3 && a.KW == 3 && a.Cin % cb == 0 && a.Ncols % 4 == 0 && total < (1ll << 31) && !a.scale && !a.shift &&
+            a.act == ACT_NONE) {
+            a.ksplit = 4; a.cps = a.Cin / cb; a.cls_rows = Nc;
+            dim3 g((unsigned)(4 * ((Nc + c.bm - 1) / c.bm)), (unsigned)((a.Ncols + c.bn - 1) / c.bn), 4u);
+            launch_tile<TR>(a, cb, c, g, st);
+            hipLaunchKernelGGL(k_conv_splitk_epilogue_cls, dim3(egrid(total / 4)), dim3(256), 0, st, workspace, Nc, a.B, a.Hd, a.Wd, a.Ncols, a.KH, a.KW, a.off,
+                               a.res, a.out, a.xin, a.dact, a.pre);
+            return;
+        }
         dim3 g((unsigned)(4 * ((Nc + c.bm - 1) / c.bm)), (unsigned)((a.Ncols + c.bn - 1) / c.bn));
         launch_tile<TR>(a, cb, c, g, st);
         return;
@@ -1790,6 +1839,15 @@ int e2e_conv_weight_layouts_batched(const long long* desc, int nlayers, void* st
 }
 
 /* floats of split-K workspace a GEMM of `rows` x `cols` with reduction length K may use (0: never splits) */
+int64_t e2e_conv2d_splitk_workspace_floats(int64_t rows, int cols, int K);
+/* workspace of a backward-data call: the split-K slabs of the stride-1 form, or the (tap, class) slabs of the stride-2 class form */
+int64_t e2e_conv2d_bwd_data_workspace_floats(int B, int Hd, int Wd, int cols, int K, int stride) {
+    const int64_t plain = e2e_conv2d_splitk_workspace_floats((int64_t)B * Hd * Wd, cols, K);
+    if (stride != 2) return plain;
+    const int64_t cls = (int64_t)16 * B * ((Hd + 1) / 2) * ((Wd + 1) / 2) * cols;      // 4 tap slices x 4 classes x the largest class
+    return cls > plain ? cls : plain;
+}
+
 int64_t e2e_conv2d_splitk_workspace_floats(int64_t rows, int cols, int K) {
     if (K % 16 != 0) return 0;
     int smax = 1;                                            // the largest slice count any chunk depth would choose
@@ -1895,7 +1953,7 @@ static int bwd_data_impl(const float* dz, const float* w_bwd, int ld_bwd, float*
     // accumulate: dxp += result -- the epilogue's residual input reads the element it is about to overwrite (same thread)
     if (accumulate) a.res = dxp;
     a.xin = in_act ? x_in : nullptr; a.dact = in_act; a.pre = pre_add;
-    launch_gemm<true>(a, 4, a.cls ? nullptr : workspace, (hipStream_t)stream);
+    launch_gemm<true>(a, 4, workspace, (hipStream_t)stream);
     E2E_LAUNCH_CHECK("e2e_conv2d_bwd_data");
     return E2E_OK;
 }

@@ -91,6 +91,7 @@ SIGNATURES = {
     "e2e_conv_weight_layouts_batched": [c_fp, c_int, c_fp],
     "e2e_conv2d_fwd": [c_fp, c_fp, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp] + [c_int] * 11 + [c_f32, c_f32, c_fp, c_fp],
     "e2e_conv2d_splitk_workspace_floats": [c_i64, c_int, c_int],
+    "e2e_conv2d_bwd_data_workspace_floats": [c_int, c_int, c_int, c_int, c_int, c_int],
     "e2e_conv_gemm_force": [c_int, c_int, c_int],
     "e2e_conv_wgrad_target": [c_int],
     "e2e_conv_gemm_choice": [c_i64, c_int, c_int, c_int, c_int, c_fp],
@@ -122,7 +123,7 @@ _RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats"
             "e2e_warp_photo_lossgrad_workspace_floats": c_i64, "e2e_pf_workspace_bytes": c_i64,
             "e2e_knn1_workspace_bytes": c_i64, "e2e_median_workspace_bytes": c_i64,
             "e2e_depth_scale_workspace_bytes": c_i64, "e2e_reduce_workspace_floats": c_i64,
-            "e2e_conv2d_wgrad_workspace_floats": c_i64, "e2e_conv2d_splitk_workspace_floats": c_i64,
+            "e2e_conv2d_wgrad_workspace_floats": c_i64, "e2e_conv2d_splitk_workspace_floats": c_i64, "e2e_conv2d_bwd_data_workspace_floats": c_i64,
             "e2e_head_workspace_floats": c_i64, "e2e_icp_workspace_bytes": c_i64, "e2e_aux_workspace_floats": c_i64,
             "e2e_affine_bwd_workspace_floats": c_i64}
 

@@ -388,7 +388,7 @@ class _Conv2d(torch.autograd.Function):
             pp = pad if pad_mode == 1 else 0
             direct = pp == 0 and up == 1 and src1 is None
             dxp = torch.empty(B, Cin, Hs + 2 * pp, Ws + 2 * pp, device=dev, dtype=torch.float32, memory_format=CL)
-            nws = L.load().e2e_conv2d_splitk_workspace_floats(B * (Hs + 2 * pp) * (Ws + 2 * pp), Cin, KH * KW * Cout)
+            nws = L.load().e2e_conv2d_bwd_data_workspace_floats(B, Hs + 2 * pp, Ws + 2 * pp, Cin, KH * KW * Cout, stride)
             ws2 = torch.empty(nws, device=dev, dtype=torch.float32) if nws else None
             L.call("e2e_conv2d_bwd_data", L.ptr(dZ), L.ptr(wb), ldb, L.ptr(dxp), B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode,
                    L.ptr(ws2), st)

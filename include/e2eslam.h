@@ -352,6 +352,9 @@ int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const f
  * slices in a fixed order.  workspace for e2e_conv2d_fwd (rows = B*Ho*Wo, cols = Cout, K = KH*KW*Cin)
  * and e2e_conv2d_bwd_data (rows = B*(Hs+2p)*(Ws+2p), cols = Cin, K = KH*KW*Cout); NULL disables it. */
 int64_t e2e_conv2d_splitk_workspace_floats(int64_t rows, int cols, int K);
+/* floats of workspace for e2e_conv2d_bwd_data* on an input-gradient domain of (B, Hd, Wd, cols) with K = KH * KW * Cout: the split-K
+ * slabs of a stride-1 layer, or the per-(tap, parity class) slabs of the stride-2 class form (4 x 4 x the largest class). */
+int64_t e2e_conv2d_bwd_data_workspace_floats(int B, int Hd, int Wd, int cols, int K, int stride);
 /* Tuning hook (tools/gemm_tune.py): force the workgroup tile (bm x bn in {64x64, 128x64, 128x128, 128x32, 32x128, 32x64,
  * 64x32, 32x32}) and the number of K slices of every following convolution GEMM; bm = 0 restores the built-in choice
  * (a cost model over tile quantisation on 256 CUs, calibrated with that tool).  Query the split-K workspace AFTER forcing. */
@@ -370,7 +373,8 @@ int e2e_conv2d_act_bwd(const float* dy, const float* y, const float* scale, floa
 int e2e_conv2d_act_bwd_acc(const float* dy, const float* y, const float* scale, float* dz, int64_t n,
                            int C, int act, int accumulate, void* stream);
 
-/* gradient wrt the virtual (padded when pad_mode == 1) input: dxp (B,Hs+2p,Ws+2p,Cin). */
+/* gradient wrt the virtual (padded when pad_mode == 1) input: dxp (B,Hs+2p,Ws+2p,Cin). 
+ * workspace: e2e_conv2d_bwd_data_workspace_floats(B, Hs + 2 pp, Ws + 2 pp, Cin, KH * KW * Cout, stride) floats (NULL: no split). */
 int e2e_conv2d_bwd_data(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs,
                         int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride,
                         int pad, int pad_mode, float* workspace, void* stream);
