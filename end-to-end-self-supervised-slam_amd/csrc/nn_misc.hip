@@ -244,7 +244,119 @@ __global__ __launch_bounds__(256) void k_upsample2_concat(const float* __restric
 
 #define AFF_SLICES 64
 
+// Max-pool with the position of the maximum kept: one byte per output element (kh * 3 + kw of the FIRST maximum in ATen's scan
+// order).  The backward then reads, per 2 x 2 input block and channel quad, the <= 4 windows' position bytes and gradients
+// (~150 bytes) instead of re-scanning a 5 x 5 patch of the input (400 bytes: 59 us for the stem's 39 MB tensor).
+__global__ __launch_bounds__(256) void k_maxpool_fwd_idx(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
+                                                         int B, int H, int W, int C, int Ho, int Wo) {
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t t = i;
+        const int c4 = (int)(t % C4); t /= C4;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho); t /= Ho;
+        const int b = (int)t;
+        f4v best = (f4v){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int arg[4] = {-1, -1, -1, -1};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int yy = 2 * oh - 1 + kh;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int xx = 2 * ow - 1 + kw;
+                if (xx < 0 || xx >= W) continue;
+                const f4v v = *(const f4v*)(x + (((int64_t)b * H + yy) * W + xx) * C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (arg[e] < 0) arg[e] = kh * 3 + kw;           // the scan starts at the first valid cell
+                    if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; arg[e] = kh * 3 + kw; }
+                }
+            }
+        }
+        *(f4v*)(y + i * 4) = best;
+        *(unsigned int*)(idx + i * 4) = (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_maxpool_bwd_idx(const float* __restrict__ x, const unsigned char* __restrict__ idx, const float* __restrict__ dy,
+                                                         float* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo, int accumulate, int mul_relu) {
+    const int C4 = C >> 2, Hb = (H + 1) >> 1, Wb = (W + 1) >> 1;
+    const int64_t total = (int64_t)B * Hb * Wb * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t t = i;
+        const int c4 = (int)(t % C4); t /= C4;
+        const int bx = (int)(t % Wb); t /= Wb;
+        const int by = (int)(t % Hb); t /= Hb;
+        const int b = (int)t;
+        f4v g[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) g[r][c] = (f4v){0.f, 0.f, 0.f, 0.f};
+        // input block rows 2 by, 2 by + 1 sit at window rows (wa = 0: kh 1, 2), (wa = 1: kh 0 for the second row only); same for columns
+#pragma unroll
+        for (int wa = 0; wa < 2; ++wa)
+#pragma unroll
+            for (int wb = 0; wb < 2; ++wb) {
+                const int oh = by + wa, ow = bx + wb;
+                if (oh >= Ho || ow >= Wo) continue;
+                const int64_t o = (((int64_t)b * Ho + oh) * Wo + ow) * C + c4 * 4;
+                const f4v gy = *(const f4v*)(dy + o);
+                const unsigned pk = *(const unsigned int*)(idx + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int a = (int)((pk >> (8 * e)) & 0xFFu);
+                    const int kh = a / 3, kw = a - kh * 3;
+                    const int r = 2 * wa + kh - 1, c = 2 * wb + kw - 1;     // position inside the 2 x 2 block (or outside it)
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc)
+                            if (r == rr && c == cc) g[rr][cc][e] += gy[e];
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int yy = 2 * by + r, xx = 2 * bx + c;
+                if (yy >= H || xx >= W) continue;
+                const int64_t o = (((int64_t)b * H + yy) * W + xx) * C + c4 * 4;
+                f4v v = g[r][c];
+                if (mul_relu) {
+                    const f4v xv = *(const f4v*)(x + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = xv[e] > 0.f ? v[e] : 0.f;
+                }
+                f4v* d = (f4v*)(dx + o);
+                if (accumulate) { const f4v old = *d; v = old + v; }
+                *d = v;
+            }
+    }
+}
+
 extern "C" {
+
+int e2e_maxpool3x3s2_fwd_idx(const float* x, float* y, unsigned char* argmax, int B, int H, int W, int C, void* stream) {
+    E2E_REQUIRE(x && y && argmax && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, E2E_ERR_ARG, "e2e_maxpool3x3s2_fwd_idx: bad argument (C %% 4 == 0)");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(k_maxpool_fwd_idx, dim3(mgrid((int64_t)B * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, argmax, B, H, W, C, Ho, Wo);
+    E2E_LAUNCH_CHECK("e2e_maxpool3x3s2_fwd_idx");
+    return E2E_OK;
+}
+
+int e2e_maxpool3x3s2_bwd_idx(const float* x, const unsigned char* argmax, const float* dy, float* dx, int B, int H, int W, int C, int accumulate,
+                             int mul_relu, void* stream) {
+    E2E_REQUIRE(argmax && dy && dx && (x || !mul_relu) && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, E2E_ERR_ARG,
+                "e2e_maxpool3x3s2_bwd_idx: bad argument (C %% 4 == 0)");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(k_maxpool_bwd_idx, dim3(mgrid((int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4), 8192)), dim3(256), 0, (hipStream_t)stream, x,
+                       argmax, dy, dx, B, H, W, C, Ho, Wo, accumulate, mul_relu);
+    E2E_LAUNCH_CHECK("e2e_maxpool3x3s2_bwd_idx");
+    return E2E_OK;
+}
 
 int e2e_maxpool3x3s2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
     E2E_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, E2E_ERR_ARG, "e2e_maxpool3x3s2_fwd: bad argument (C %% 4 == 0)");

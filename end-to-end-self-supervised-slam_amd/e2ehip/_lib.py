@@ -108,6 +108,8 @@ SIGNATURES = {
     "e2e_conv2d_bwd_weight": [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp] + [c_int] * 13 + [c_f32, c_f32, c_fp],
     "e2e_maxpool3x3s2_fwd": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp],
     "e2e_maxpool3x3s2_bwd": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp],
+    "e2e_maxpool3x3s2_fwd_idx": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp],
+    "e2e_maxpool3x3s2_bwd_idx": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp],
     "e2e_bn_fold": [c_fp, c_fp, c_fp, c_fp, c_f32, c_fp, c_fp, c_fp, c_int, c_fp],
     "e2e_affine_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_i64, c_int, c_fp],
     "e2e_affine_bwd_workspace_floats": [c_int],

@@ -168,16 +168,18 @@ class _MaxPool:
     def __init__(self, plan, src):
         self.src = src
         self.out = Buf(src.B, (src.h - 1) // 2 + 1, (src.w - 1) // 2 + 1, src.C, plan.dev)
+        self.argmax = torch.empty(self.out.t.shape, device=plan.dev, dtype=torch.uint8)      # window position of every maximum, for the backward
 
     def fwd(self, plan, st):
         s = self.src
-        L.call("e2e_maxpool3x3s2_fwd", L.ptr(s.t), L.ptr(self.out.t), s.B, s.h, s.w, s.C, st)
+        L.call("e2e_maxpool3x3s2_fwd_idx", L.ptr(s.t), L.ptr(self.out.t), L.ptr(self.argmax), s.B, s.h, s.w, s.C, st)
 
     def bwd(self, plan, st):
         s = self.src
         if s.act not in (0, ACT["relu"]):
             raise NotImplementedError("launch plan: the max-pool follows a ReLU (ResNet stem)")
-        L.call("e2e_maxpool3x3s2_bwd", L.ptr(s.t), L.ptr(self.out.g), L.ptr(s.g), s.B, s.h, s.w, s.C, 1 if s.written else 0, 1 if s.act else 0, st)
+        L.call("e2e_maxpool3x3s2_bwd_idx", L.ptr(s.t), L.ptr(self.argmax), L.ptr(self.out.g), L.ptr(s.g), s.B, s.h, s.w, s.C, 1 if s.written else 0,
+               1 if s.act else 0, st)
         s.written = True
 
 

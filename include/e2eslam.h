@@ -432,6 +432,12 @@ int e2e_conv2d_bwd_weight_scaled(const float* da, const float* out_scale, const 
 int e2e_maxpool3x3s2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
 int e2e_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C,
                          int accumulate, int mul_relu, void* stream);
+/* The same pair with the position of each window's maximum kept in one byte per output element (argmax (B,Ho,Wo,C) uint8 = kh * 3 + kw
+ * of the first maximum in ATen's scan order): the backward reads the <= 4 windows' bytes instead of re-scanning the input (the launch
+ * plan's form; x is only read for mul_relu). */
+int e2e_maxpool3x3s2_fwd_idx(const float* x, float* y, unsigned char* argmax, int B, int H, int W, int C, void* stream);
+int e2e_maxpool3x3s2_bwd_idx(const float* x, const unsigned char* argmax, const float* dy, float* dx, int B, int H, int W, int C,
+                             int accumulate, int mul_relu, void* stream);
 
 /* eval-mode BatchNorm with a TRAINABLE affine (the reference freezes parameters whose name contains "bn",
  * online_adaption.py:182-184, so encoder.layerN.0.downsample.1 keeps training): scale = gamma / sqrt(var + eps),

@@ -28,6 +28,31 @@ def test_maxpool_fwd_bwd_matches_torch(B, C, H, W):
     torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=0, atol=0)    # sums of at most 4 identical addends in window order... exact here
 
 
+@pytest.mark.parametrize("B,C,H,W,acc,relu", [(2, 64, 24, 32, 0, 1), (1, 16, 7, 9, 1, 0), (1, 64, 240, 320, 0, 1)])
+def test_maxpool_with_kept_positions_matches_torch(B, C, H, W, acc, relu):
+    """e2e_maxpool3x3s2_fwd_idx / _bwd_idx (the launch plan's pair): same values and gradients as ATen, with the accumulate flag and the
+    fused ReLU mask of the producer (d/d pre-activation of the stem)."""
+    from e2ehip import _lib as L
+    g = torch.Generator().manual_seed(3)
+    x = torch.relu(torch.randn(B, C, H, W, generator=g))
+    x[:, :, ::5] = x[:, :, 1::5][:, :, : x[:, :, ::5].shape[2]]
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    want = xr.grad * (x > 0) if relu else xr.grad
+    base = torch.randn(x.shape, generator=g)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)                      # NHWC
+    Ho, Wo = yr.shape[2:]
+    yd = torch.empty(B, Ho, Wo, C, device=DEV)
+    idx = torch.empty(B, Ho, Wo, C, device=DEV, dtype=torch.uint8)
+    dx = base.permute(0, 2, 3, 1).contiguous().to(DEV)
+    L.call("e2e_maxpool3x3s2_fwd_idx", L.ptr(xd), L.ptr(yd), L.ptr(idx), B, H, W, C, L.stream())
+    L.call("e2e_maxpool3x3s2_bwd_idx", L.ptr(xd), L.ptr(idx), L.ptr(gy.permute(0, 2, 3, 1).contiguous().to(DEV)), L.ptr(dx), B, H, W, C, acc, relu, L.stream())
+    assert torch.equal(yd.permute(0, 3, 1, 2).cpu(), yr.detach())
+    torch.testing.assert_close(dx.permute(0, 3, 1, 2).cpu(), want + base if acc else want, rtol=0, atol=1e-6 if acc else 0)
+
+
 @pytest.mark.parametrize("relu,res", [(False, False), (True, True), (True, False)])
 def test_trainable_eval_bn_behind_conv(relu, res):
     """BN(conv(x)) [+ residual] [ReLU] with eval statistics and TRAINABLE gamma / beta: values and all four gradients."""
