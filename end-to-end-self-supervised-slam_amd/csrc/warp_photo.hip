@@ -147,7 +147,7 @@ __global__ void k_grid_sample_fwd(const float* __restrict__ in, e2e_strides s, c
 template <int PAD, bool ALIGN>
 __global__ void k_grid_sample_bwd(const float* __restrict__ in, e2e_strides s, const float* __restrict__ grid,
                                   const float* __restrict__ gout, float* __restrict__ ggrid,
-                                  float* __restrict__ gin, int C, int Hi, int Wi, int Ho, int Wo) {
+                                  float* __restrict__ gin, int C, int Hi, int Wi, int Ho, int Wo, unsigned long long* __restrict__ gin_fx) {
     const int No = Ho * Wo;
     const int b = blockIdx.y;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < No; i += gridDim.x * blockDim.x) {
@@ -168,7 +168,14 @@ __global__ void k_grid_sample_bwd(const float* __restrict__ in, e2e_strides s, c
             const float se = (bl.in_y1 & bl.in_x1) ? pc[s.sh + s.sw] : 0.f;
             gix += g * ((ne - nw) * (1.f - bl.ty) + (se - sw) * bl.ty);
             giy += g * ((sw - nw) * (1.f - bl.tx) + (se - ne) * bl.tx);
-            if (gin) {  // scatter-add into a contiguous (B,C,Hi,Wi) gradient image
+            if (gin_fx) {  // scatter-add into a (B,C,Hi,Wi) image of 2^-48 fixed-point sums: integer adds commute, so the result does
+                // not depend on the arrival order (bitwise reproducible; |sum| < 32768, resolution 3.6e-15)
+                unsigned long long* gi = gin_fx + (((int64_t)b * C + c) * Hi + bl.y0) * Wi + bl.x0;
+                if (bl.in_y0 & bl.in_x0) atomicAdd(gi, (unsigned long long)__double2ll_rn((double)(g * bl.wnw) * 281474976710656.0));
+                if (bl.in_y0 & bl.in_x1) atomicAdd(gi + 1, (unsigned long long)__double2ll_rn((double)(g * bl.wne) * 281474976710656.0));
+                if (bl.in_y1 & bl.in_x0) atomicAdd(gi + Wi, (unsigned long long)__double2ll_rn((double)(g * bl.wsw) * 281474976710656.0));
+                if (bl.in_y1 & bl.in_x1) atomicAdd(gi + Wi + 1, (unsigned long long)__double2ll_rn((double)(g * bl.wse) * 281474976710656.0));
+            } else if (gin) {  // floating-point scatter-add: run-to-run differences in the last bits (kept for callers without scratch)
                 float* gi = gin + (((int64_t)b * C + c) * Hi + bl.y0) * Wi + bl.x0;
                 if (bl.in_y0 & bl.in_x0) atomicAdd(gi, g * bl.wnw);
                 if (bl.in_y0 & bl.in_x1) atomicAdd(gi + 1, g * bl.wne);
@@ -688,8 +695,30 @@ int e2e_grid_sample_bwd(const float* input, e2e_strides in_strides, const float*
     E2E_REQUIRE(padding_mode == E2E_PADDING_BORDER || padding_mode == E2E_PADDING_ZEROS, E2E_ERR_ARG,
                 "e2e_grid_sample_bwd: padding_mode %d not supported (zeros|border)", padding_mode);
     DISPATCH_PAD_ALIGN(k_grid_sample_bwd, flat_grid(B, (int64_t)Ho * Wo), dim3(256), 0, (hipStream_t)stream, input,
-                       in_strides, grid, g_out, g_grid, g_input, C, Hi, Wi, Ho, Wo);
+                       in_strides, grid, g_out, g_grid, g_input, C, Hi, Wi, Ho, Wo, (unsigned long long*)nullptr);
     E2E_LAUNCH_CHECK("e2e_grid_sample_bwd");
+    return E2E_OK;
+}
+
+__global__ void k_fixed48_to_float(const long long* __restrict__ fx, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)((double)fx[i] * (1.0 / 281474976710656.0));
+}
+
+int e2e_grid_sample_bwd_exact(const float* input, e2e_strides in_strides, const float* grid, const float* g_out, float* g_grid,
+                              long long* g_input_fixed, float* g_input, int B, int C, int Hi, int Wi, int Ho, int Wo, int padding_mode,
+                              int align_corners, void* stream) {
+    E2E_REQUIRE(B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, E2E_ERR_ARG, "e2e_grid_sample_bwd_exact: bad dims");
+    E2E_REQUIRE(input && grid && g_out && g_grid && g_input_fixed && g_input, E2E_ERR_ARG, "e2e_grid_sample_bwd_exact: null pointer");
+    E2E_REQUIRE(padding_mode == E2E_PADDING_BORDER || padding_mode == E2E_PADDING_ZEROS, E2E_ERR_ARG,
+                "e2e_grid_sample_bwd_exact: padding_mode %d not supported (zeros|border)", padding_mode);
+    const int64_t n = (int64_t)B * C * Hi * Wi;
+    (void)hipMemsetAsync(g_input_fixed, 0, (size_t)n * sizeof(long long), (hipStream_t)stream);
+    DISPATCH_PAD_ALIGN(k_grid_sample_bwd, flat_grid(B, (int64_t)Ho * Wo), dim3(256), 0, (hipStream_t)stream, input,
+                       in_strides, grid, g_out, g_grid, g_input, C, Hi, Wi, Ho, Wo, (unsigned long long*)g_input_fixed);
+    hipLaunchKernelGGL(k_fixed48_to_float, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       g_input_fixed, g_input, n);
+    E2E_LAUNCH_CHECK("e2e_grid_sample_bwd_exact");
     return E2E_OK;
 }
 

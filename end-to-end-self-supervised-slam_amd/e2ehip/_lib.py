@@ -35,6 +35,7 @@ SIGNATURES = {
     "e2e_project3d_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp],
     "e2e_grid_sample_fwd": [c_fp, Strides, c_fp, c_fp] + [c_int] * 8 + [c_fp],
     "e2e_grid_sample_bwd": [c_fp, Strides, c_fp, c_fp, c_fp, c_fp] + [c_int] * 8 + [c_fp],
+    "e2e_grid_sample_bwd_exact": [c_fp, Strides, c_fp, c_fp, c_fp, c_fp, c_fp] + [c_int] * 8 + [c_fp],
     "e2e_photometric_fwd": [c_fp, Strides, c_fp, Strides, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp],
     "e2e_photometric_bwd": [c_fp, Strides, c_fp, Strides, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp],
     "e2e_warp_photo_workspace_floats": [c_int, c_int, c_int],

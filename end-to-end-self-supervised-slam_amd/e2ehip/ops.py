@@ -111,10 +111,15 @@ class _GridSample(torch.autograd.Function):
         _, Ho, Wo, _ = grid.shape
         g = g.contiguous()
         gg = torch.empty_like(grid)
-        gi = torch.zeros(B, C, Hi, Wi, device=g.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        L.call("e2e_grid_sample_bwd", L.ptr(inp), L.strides4(inp), L.ptr(grid), L.ptr(g), L.ptr(gg), L.ptr(gi),
+        if ctx.needs_input_grad[0]:      # gradient wrt the sampled image: a scatter -- fixed-point integer accumulation, bitwise reproducible
+            gi = torch.empty(B, C, Hi, Wi, device=g.device, dtype=torch.float32)
+            fx = torch.empty(B, C, Hi, Wi, device=g.device, dtype=torch.int64)
+            L.call("e2e_grid_sample_bwd_exact", L.ptr(inp), L.strides4(inp), L.ptr(grid), L.ptr(g), L.ptr(gg), L.ptr(fx), L.ptr(gi),
+                   B, C, Hi, Wi, Ho, Wo, pad, align, L.stream())
+            return gi, gg, None, None
+        L.call("e2e_grid_sample_bwd", L.ptr(inp), L.strides4(inp), L.ptr(grid), L.ptr(g), L.ptr(gg), None,
                B, C, Hi, Wi, Ho, Wo, pad, align, L.stream())
-        return gi, gg, None, None
+        return None, gg, None, None
 
 
 def grid_sample(input, grid, mode="bilinear", padding_mode="zeros", align_corners=False):

@@ -330,3 +330,27 @@ def test_lossgrad_chain_keeps_non_finite_losses_visible_and_tiny_images():
         ch.step_chain(1)
         ch.flush_chain(1, out2)
         assert torch.isfinite(out2[0])
+
+
+@pytest.mark.parametrize("pad,align", [("border", False), ("zeros", True)])
+def test_grid_sample_input_gradient_matches_torch_and_is_bitwise_reproducible(pad, align):
+    """d/d(sampled image) of grid_sample (the adjoint of a data-dependent bilinear gather = a scatter; LOSS.geometric's interpolated
+    source depth, online_adaption.py:436-439): values against torch's CPU F.grid_sample backward, and two runs bit for bit -- the
+    contributions are accumulated as fixed-point integers (e2e_grid_sample_bwd_exact), so arrival order does not matter."""
+    import torch.nn.functional as F
+    from e2ehip import ops
+    g = torch.Generator().manual_seed(4)
+    B, C, H, W = 2, 3, 40, 56
+    img = torch.randn(B, C, H, W, generator=g)
+    grid = (torch.rand(B, H, W, 2, generator=g) * 2.4 - 1.2)                 # incl. out-of-range samples
+    gout = torch.randn(B, C, H, W, generator=g)
+    ir, gr = img.clone().requires_grad_(True), grid.clone().requires_grad_(True)
+    F.grid_sample(ir, gr, mode="bilinear", padding_mode=pad, align_corners=align).backward(gout)
+    runs = []
+    for _ in range(2):
+        idv, gdv = img.to(DEV).requires_grad_(True), grid.to(DEV).requires_grad_(True)
+        ops.grid_sample(idv, gdv, padding_mode=pad, align_corners=align).backward(gout.to(DEV))
+        runs.append((idv.grad.clone(), gdv.grad.clone()))
+    torch.testing.assert_close(runs[0][0].cpu(), ir.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(runs[0][1].cpu(), gr.grad, rtol=1e-4, atol=1e-4)
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
