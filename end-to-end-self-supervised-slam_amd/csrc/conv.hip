@@ -1261,7 +1261,9 @@ __global__ __launch_bounds__(256) void k_wgrad7x7_stem(StemWgradArgs a) {
 #pragma unroll
     for (int nt = 0; nt < 10; ++nt) {
         const int k = 16 * nt + l16;                         // columns 147 .. 159 read valid patch cells and are never stored
-        offn[nt] = k + (k / 21) * (ROW - 21) + 6 * kq;       // + this lane's pixel of the MFMA's 4
+        offn[nt] = k + (k / 21) * (ROW - 21) + 48 * kq;      // + this lane's pixel of the MFMA's 4: pixels ks, ks + 8, ks + 16, ks + 24 of the row
+                                                             // (48 floats apart = 16 banks: the two k-groups of a half-wave read disjoint banks;
+                                                             // adjacent pixels, 6 floats apart, gave a 39 % conflict rate)
     }
     f4v acc[10];
 #pragma unroll
@@ -1287,13 +1289,13 @@ __global__ __launch_bounds__(256) void k_wgrad7x7_stem(StemWgradArgs a) {
         __syncthreads();
 #pragma unroll 1
         for (int r = 0; r < TH; ++r) {
-            const float* ap = dzs + (r * TW + kq) * 64 + 16 * wave + l16;        // A[m = co][k = pixel 4 ks + kq]
+            const float* ap = dzs + (r * TW + 8 * kq) * 64 + 16 * wave + l16;    // A[m = co][k = pixel ks + 8 kq]
             const float* bp = patch + 2 * r * ROW;                               // B[k = pixel][n]: patch(pixel, column 16 nt + l16)
 #pragma unroll 2
             for (int ks = 0; ks < TW / 4; ++ks) {
-                const float av = ap[ks * 256];
+                const float av = ap[ks * 64];
 #pragma unroll
-                for (int nt = 0; nt < 10; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[offn[nt] + ks * 24], acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < 10; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[offn[nt] + ks * 6], acc[nt], 0, 0, 0);
             }
         }
     }
@@ -1395,7 +1397,7 @@ __global__ __launch_bounds__(256) void k_weight_layouts_batched(const long long*
     const float* __restrict__ bsc = (const float*)d[9];
     const int T = KH * KW;
     constexpr int TMAX = 9, TS = 32;
-    __shared__ float tile[TMAX][TS][TS + 1];
+    __shared__ float tile[TMAX][TS + 1][TS + 1];           // tap stride 33 * 33 = 1 mod 32 banks: the staging store walks taps fastest (PMC: 54 % conflicts with [TS][TS + 1])
     if (T > TMAX) {                                           // the 7x7 stem (Cin = 3): element-wise, it is tiny
         const int64_t total = (int64_t)Cout * Cin * T;
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
