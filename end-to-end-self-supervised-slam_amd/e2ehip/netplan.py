@@ -217,6 +217,9 @@ class NetPlan:
         from depth_estimation.networks import BasicBlock
         self.model, self.dev, self.overlap = model, torch.device(device), overlap
         self.B, self.H, self.W = B, H, W
+        if H % 32 or W % 32:
+            raise ValueError(f"launch plan: the encoder halves the image five times and the decoder doubles it back before every skip "
+                             f"concatenation (networks.py:277-292): height and width must be multiples of 32, got {H} x {W}")
         self.ops, self._sinks, self._side = [], {}, None
         enc, dec = model.encoder.encoder, model.decoder
         if any(m.training for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)):
