@@ -188,7 +188,7 @@ def seq_bench(a, rank, world, dev):
     barrier()
     assert slam.refinement_steps_done - done0 == K
     if world > 1:
-        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        tt = torch.tensor([el], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     map_points = int(slam.map.M)
@@ -407,11 +407,17 @@ def main():
     if a.dry:
         return dry_run(a, rank, world)
     import torch
-    dev = torch.device("cuda", local)
+    # E2E_REHEARSE_ONE_GPU=1: every rank on cuda:0 with gloo as transport (the gradient bucket is staged through the host) -- a rehearsal
+    # of the N-rank GPU code path (graphs split around the exchange, idle rounds, map gather) on a one-GPU box; never a measurement
+    rehearse = os.environ.get("E2E_REHEARSE_ONE_GPU") == "1"
+    dev = torch.device("cuda", 0 if rehearse else local)
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     if a.workload == "warp":
         return warp_bench(a, rank, world, dev)
     return seq_bench(a, rank, world, dev)

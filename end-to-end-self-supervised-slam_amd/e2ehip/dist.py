@@ -13,6 +13,30 @@ def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _host_staged():
+    """gloo carrying GPU tensors (bench.py's one-GPU rehearsal of the N-rank path): collectives run on host copies."""
+    return dist.get_backend() == "gloo"
+
+
+def _all_reduce(t, op):
+    if t.is_cuda and _host_staged():
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+
+
+def _all_gather(outs, t):
+    if t.is_cuda and _host_staged():
+        hs = [o.cpu() for o in outs]
+        dist.all_gather(hs, t.cpu())
+        for o, h in zip(outs, hs):
+            o.copy_(h)
+    else:
+        dist.all_gather(outs, t)
+
+
 def exchange_gradients_(flat, participating=True):
     """The ONE collective of a refinement step (between loss.backward() and optimizer.step(), online_adaption.py:539-540):
     all-reduce(SUM) of FusedAdam's flat gradient bucket.  Keyframe decisions are data dependent (online_adaption.py:234), so a
@@ -24,7 +48,7 @@ def exchange_gradients_(flat, participating=True):
         flat.grad_ext.zero_()
     flat.grad_ext[flat.numel] = 1.0 if participating else 0.0
     if world() > 1:
-        dist.all_reduce(flat.grad_ext, op=dist.ReduceOp.SUM)
+        _all_reduce(flat.grad_ext, dist.ReduceOp.SUM)
     return flat.grad_ext[flat.numel:flat.numel + 1]
 
 
@@ -36,7 +60,7 @@ def allreduce_mean_(flat_grad, participating=True):
     ext = torch.empty(flat_grad.numel() + 1, device=flat_grad.device, dtype=flat_grad.dtype)
     ext[:-1] = flat_grad.reshape(-1) if participating else 0.0
     ext[-1] = 1.0 if participating else 0.0
-    dist.all_reduce(ext, op=dist.ReduceOp.SUM)
+    _all_reduce(ext, dist.ReduceOp.SUM)
     flat_grad.copy_((ext[:-1] / ext[-1].clamp(min=1.0)).view_as(flat_grad))
     return flat_grad
 
@@ -47,7 +71,7 @@ def common_rounds(n_local, device):
     if world() == 1:
         return int(n_local)
     t = torch.tensor([int(n_local)], device=device, dtype=torch.int64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    _all_reduce(t, dist.ReduceOp.MAX)
     return int(t.item())
 
 
@@ -58,12 +82,12 @@ def gather_maps(points, normals, colors, ccounts):
     dev = points.device
     n = torch.tensor([points.shape[0]], device=dev, dtype=torch.int64)
     counts = [torch.zeros_like(n) for _ in range(world())]
-    dist.all_gather(counts, n)
+    _all_gather(counts, n)
     counts = torch.cat(counts)
     cap = int(counts.max())
     packed = torch.zeros(cap, 10, device=dev, dtype=torch.float32)          # 40 B per point
     packed[: points.shape[0]] = torch.cat([points, normals, colors, ccounts.reshape(-1, 1)], 1)
     parts = [torch.empty_like(packed) for _ in range(world())]
-    dist.all_gather(parts, packed)
+    _all_gather(parts, packed)
     full = torch.cat([p[: int(c)] for p, c in zip(parts, counts)], 0)
     return full[:, 0:3], full[:, 3:6], full[:, 6:9], full[:, 9], counts.cpu()
