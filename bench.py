@@ -193,6 +193,11 @@ def seq_bench(a, rank, world, dev):
         el = float(tt.item())
     map_points = int(slam.map.M)
     ate = slam.absolute_trajectory_error() if a.odom != "gt" else None
+    if world > 1:                                       # data parallel: the shared depth network must be bit-identical on every rank
+        cs = slam.optimizer.flat.data.double().sum().reshape(1).to("cpu" if dist.get_backend() == "gloo" else dev)
+        allcs = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(allcs, cs)
+        assert all(float(c) == float(allcs[0]) for c in allcs), f"ranks disagree about the network parameters: {[float(c) for c in allcs]}"
 
     # ---- per-kernel durations of ONE more keyframe, measured live with HIP events on the launch streams --------------
     roof = {}

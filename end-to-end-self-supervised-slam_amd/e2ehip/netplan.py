@@ -242,6 +242,8 @@ class NetPlan:
         feats = [f]
         x = self._add(_MaxPool(self, f))
         for stage in (enc.layer1, enc.layer2, enc.layer3, enc.layer4):
+            if stage is enc.layer4:
+                self.split_index = len(self.ops)   # backward of ops[split_index:] (head, decoder, layer4) = 80 % of the gradient bucket, done first
             for blk in stage:
                 if not isinstance(blk, BasicBlock):
                     raise NotImplementedError("launch plan: BasicBlock encoders (ResNet-18 / 34)")
@@ -346,9 +348,42 @@ class NetPlan:
         go to their sinks; joins the side stream before returning."""
         if g_disp is not None:
             self.disp.g.copy_(g_disp.reshape(self.disp.g.shape))
+        self.backward_late_layers()
+        self.backward_early_layers()
+
+    def backward_late_layers(self):
+        """First part of the backward pass: head, decoder and layer4 -- the layers whose parameters form the tail of the optimiser's
+        bucket (split_offset): data-parallel runs start that segment's all-reduce while the rest of the backward runs."""
         st = L.stream()
         for op in self.ops:
             op.out.written = False
-        for op in reversed(self.ops):
+        for op in reversed(self.ops[self.split_index:]):
             op.bwd(self, st)
         self.join()
+
+    def backward_early_layers(self):
+        st = L.stream()
+        for op in reversed(self.ops[:self.split_index]):
+            op.bwd(self, st)
+        self.join()
+
+    def split_offset(self, flat):
+        """Offset in the flat parameter / gradient bucket where the parameters of ops[split_index:] begin; checks that they ARE the
+        bucket's tail (the bucket follows the module order: stem, layer1..4, decoder)."""
+        off_of = {id(p): o for p, o in zip(flat.params, flat.offsets)}
+
+        def params_of(ops):
+            out = []
+            for op in ops:
+                for name in ("weight", "bias"):
+                    p = getattr(op, name, None)
+                    if isinstance(p, torch.nn.Parameter) and p.requires_grad and id(p) in off_of:
+                        out.append(off_of[id(p)])
+                bn = getattr(op, "bn", None)
+                if bn is not None:
+                    out += [off_of[id(p)] for p in (bn.weight, bn.bias) if p.requires_grad and id(p) in off_of]
+            return out
+        late, early = params_of(self.ops[self.split_index:]), params_of(self.ops[:self.split_index])
+        if not late or not early or min(late) <= max(early):
+            raise RuntimeError("launch plan: the late layers' parameters are not the tail of the flat bucket")
+        return min(late)

@@ -48,6 +48,7 @@ class RefineStepPlan:
         self.ws_scale = torch.empty(lib.e2e_depth_scale_workspace_bytes(), device=self.dev, dtype=torch.uint8)
         self.g_depth = torch.zeros(2, 1, H, W, **f)                 # [d loss / d depth_src, d loss / d depth_tgt]
         self.reg = reg_kind
+        self._split = None                                          # bucket offset of the late layers' parameters (data-parallel exchange)
         self.loss = LossGradPlan(1, H, W, self.dev, padding_mode, use_mask, reg_kind, 1.0, float(w_reg) if reg_kind else 0.0)
         self.loss.g_depth_src, self.loss.g_depth_tgt = self.g_depth[0:1], self.g_depth[1:2]
         src, tgt = self.colors[0:1].permute(0, 3, 1, 2), self.colors[1:2].permute(0, 3, 1, 2)       # NHWC memory, NCHW views
@@ -96,7 +97,9 @@ class RefineStepPlan:
         self._gstream.wait_stream(cur)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(self._gstream):
-            with torch.cuda.graph(g, stream=self._gstream):         # ... then the same launches recorded (not executed) for the next ones
+            # ... then the same launches recorded (not executed) for the next ones.  thread_local: in data-parallel runs a collective may
+            # be in flight on the communication stream and its watchdog thread queries events -- legal outside the capturing thread
+            with torch.cuda.graph(g, stream=self._gstream, capture_error_mode="thread_local"):
                 fn()
         cur.wait_stream(self._gstream)
         self._graphs[key] = g
@@ -122,13 +125,16 @@ class RefineStepPlan:
         L.call("e2e_transform_points", L.ptr(self.g_moved), L.ptr(self.T), L.ptr(self.g_cloud), N, 1, st)
         L.call("e2e_vertex_maps_bwd", L.ptr(d), L.ptr(self.K), L.ptr(self.pose_tgt), None, L.ptr(self.g_cloud), L.ptr(self.g3), 1, self.H, self.W, st)
 
-    def _backward(self, use_3d, with_adam):
+    def _backward(self, use_3d, with_adam, late_only=False):
         st = L.stream()
         self.loss.step()                                            # losses -> self.loss.loss[0..1]; d/d depth -> self.g_depth
         if use_3d:                                                  # g_depth_tgt += d(w_3d * l3)/d depth_tgt
             L.call("e2e_conv2d_act_bwd_acc", L.ptr(self.g3), L.ptr(self.g3), None, L.ptr(self.g_depth[1:2]), self.N, 1, 0, 1, st)
         L.call("e2e_depth_scale_bwd", L.ptr(self.g_depth), L.ptr(self.delta), L.ptr(self.median_gt), L.ptr(self.md), L.ptr(self.net.disp.g),
                L.ptr(self.ws_scale), self.g_depth.numel(), st)
+        if late_only:                                               # data-parallel runs: head, decoder, layer4 -- the bucket's tail
+            self.net.backward_late_layers()
+            return
         self.net.backward()
         if with_adam:
             self._adam()
@@ -147,17 +153,27 @@ class RefineStepPlan:
             self.init.copy_(self.delta)
         if use_3d:
             self._loss3d(knn_index)
-        multi = edist.world() > 1
-        self._run(("bwd", use_3d, not multi), lambda: self._backward(use_3d, not multi))
-        if multi:
-            edist.exchange_gradients_(self.opt.flat, True)
+        if edist.world() == 1:
+            self._run(("bwd", use_3d, True), lambda: self._backward(use_3d, True))
+        else:
+            # data-parallel: the exchange of the bucket's tail (head, decoder, layer4: 80 % of the bytes, complete after the first
+            # part of the backward pass) travels while the early layers' backward computes; then the remaining 20 %, then Adam
+            if self._split is None:
+                self._split = self.net.split_offset(self.opt.flat)
+            self._run(("bwd_late", use_3d), lambda: self._backward(use_3d, False, late_only=True))
+            handle = edist.exchange_gradients_late_(self.opt.flat, self._split, True)
+            self._run("bwd_early", self.net.backward_early_layers)
+            edist.exchange_gradients_early_(self.opt.flat, self._split, handle, True)
             self._run("adam", self._adam)
         e2e_conv.WEIGHT_EPOCH[0] += 1                               # parameters changed behind torch's version counters (module-path caches)
         self.net._epoch = e2e_conv.WEIGHT_EPOCH[0]
 
     def idle_step(self):
         """A step of a rank without a keyframe in this round (data-parallel runs): zero bucket in, averaged update out."""
-        edist.exchange_gradients_(self.opt.flat, False)
+        if self._split is None:
+            self._split = self.net.split_offset(self.opt.flat)
+        handle = edist.exchange_gradients_late_(self.opt.flat, self._split, False)      # the same two collectives as a participating rank
+        edist.exchange_gradients_early_(self.opt.flat, self._split, handle, False)
         self._run("adam", self._adam)
         e2e_conv.WEIGHT_EPOCH[0] += 1
         self.net._epoch = e2e_conv.WEIGHT_EPOCH[0]

@@ -167,6 +167,7 @@ class SLAM:
             self._step_plan()
         elif edist.world() > 1:
             self.optimizer.prebuild(self.models["depth"].used_parameters())
+            edist.broadcast_parameters_(self.optimizer.flat)
         for i in range(rounds):
             if i < len(schedule):
                 self.refinement(*schedule[i], next_pair=schedule[i + 1] if i + 1 < len(schedule) else None)
@@ -220,6 +221,9 @@ class SLAM:
                                             overlap=self.overlap_wgrad, use_graphs=self.use_graphs)
             self._inv_K = torch.pinverse(self.intrinsics[0, 0])
             self._poses_h = self.poses.detach().cpu()
+            if edist.world() > 1:                   # one shared depth network: start from rank 0's parameters
+                edist.broadcast_parameters_(self.optimizer.flat)
+                self.step_plan.net.refresh_layouts()
         self.step_plan.net.overlap = self.overlap_wgrad
         return self.step_plan
 
