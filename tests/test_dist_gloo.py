@@ -61,7 +61,22 @@ def _worker(rank, world, port, q):
     gp, gn, gc, gcc, counts = edist.gather_maps(P, Nn, C, cc)
     ok5 = gp.shape[0] == sum(r + 2 for r in range(world)) and counts.tolist() == [r + 2 for r in range(world)] and \
         torch.equal(gp[:2], torch.zeros(2, 3)) and torch.equal(gp[2:], torch.ones(3, 3)) and torch.equal(gcc, torch.tensor([0., 1, 0, 1, 2]))
-    q.put((rank, ok1, ok2, ok3, ok4, ok5))
+    # (6) the launch plan's two-segment form: tail [split, end) + participant count asynchronously, then the head [0, split);
+    #     rank 1 idles (zero bucket) -- and the parameter broadcast that makes the replicas start identical
+    flat.zero_grad()
+    split = flat.offsets[1]
+    if rank == 0:
+        sum((4.0 * p).sum() for p in ps).backward()
+    h = edist.exchange_gradients_late_(flat, split, participating=(rank == 0))
+    cnt = edist.exchange_gradients_early_(flat, split, h, participating=(rank == 0))
+    ok6 = float(cnt) == 1.0 and all(torch.allclose(p.grad, torch.full_like(p, 4.0)) for p in ps)
+    with torch.no_grad():
+        flat.data.add_(float(rank))                  # replicas drift apart ...
+    edist.broadcast_parameters_(flat)                # ... rank 0's parameters win
+    ref = [torch.zeros_like(flat.data) for _ in range(world)]
+    dist.all_gather(ref, flat.data)
+    ok6 = ok6 and all(torch.equal(r, ref[0]) for r in ref)
+    q.put((rank, ok1, ok2, ok3, ok4, ok5, ok6))
     dist.destroy_process_group()
 
 
@@ -76,7 +91,7 @@ def test_two_rank_gloo_exchange():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert sorted(res) == [(0, True, True, True, True, True), (1, True, True, True, True, True)], res
+    assert sorted(res) == [(0,) + (True,) * 6, (1,) + (True,) * 6], res
 
 
 def test_single_process_is_identity():
