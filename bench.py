@@ -228,6 +228,8 @@ def seq_bench(a, rank, world, dev):
                 "bound": "mfma", "kernel": "depth-network convolution GEMMs (k_conv_gemm forward / backward-data, k_wgrad_gemm* backward-weight incl. their "
                                            "split-K / slab reductions), fp32 v_mfma_f32_32x32x2_f32",
                 "achieved": tf, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFS, "traffic": traffic,
+                "sustained_peak_note": "pure fp32-MFMA launches of GEMM shape sustain 124-126 TFLOP/s on this part (scratch/mfma_grid.hip, "
+                                       "profiles/r02_mfma_grid_microbench.txt); frac uses the nominal 157.3",
                 "traffic_note": "bytes per C-ABI convolution call (a call = GEMM + its split-K / slab reduction), profiles/r02_bench_pmc_traffic.json",
                 "launches": conv_calls, "avg_launch_us": 1e3 * conv_ms / max(conv_calls, 1), "algorithmic_gflop_per_keyframe": conv_fl / 1e9,
                 "ms_per_keyframe": conv_ms, "share_of_event_timed_kernel_time": conv_ms / all_ms,
