@@ -479,10 +479,13 @@ __global__ __launch_bounds__(256) void k_conv3x3_thin(ThinArgs a) {
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int j = 0; j < KQ; ++j) wreg[t][j] = a.w[(int64_t)((a.flip ? 8 - t : t) * CIN + 4 * j + kq) * a.ldw + l16];
-    // ---- stage the patch: pixel-fastest thread mapping (conflict-free LDS stores), one 16-byte channel quad per load --------
+    // ---- stage the patch: one 16-byte channel quad per load --------------------------------------------------------------------
     const float* sb = a.src + (int64_t)b * a.Hsrc * a.Wsrc * CIN;
     for (int idx = tid; idx < PH * PW * KQ; idx += 256) {
-        const int pix = idx % (PH * PW), q = idx / (PH * PW);
+        // thread -> (pixel, channel quad): quad-fastest gives coalesced global loads at the price of KQ-way conflicts on the transposing
+        // LDS stores -- measured faster without the upsample (upconv(0,0) forward 36.0 -> 31.6 us, upconv(0,1) backward-data 48.1 -> 44.6);
+        // behind the x2 upsample two neighbouring pixels share a source pixel and pixel-fastest wins (43.2 vs 44.8 us)
+        const int q = (UP == 2) ? idx / (PH * PW) : idx % KQ, pix = (UP == 2) ? idx % (PH * PW) : idx / KQ;
         const int py = pix / PW, px = pix - py * PW;
         int Y = y0 - a.org + py, X = x0 - a.org + px;
         bool ok = true;
