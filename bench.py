@@ -35,6 +35,23 @@ MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA, dense (= the
 CONV_ENTRY_POINTS = ("e2e_conv2d_fwd", "e2e_conv2d_bwd_data", "e2e_conv2d_bwd_data_acc", "e2e_conv2d_bwd_data_fused", "e2e_conv2d_bwd_weight",
                      "e2e_conv2d_bwd_weight_scaled")
 WARP_ENTRY_POINTS = ("e2e_warp_photo_lossgrad_hostgeo", "e2e_warp_photo_lossgrad", "e2e_warp_photo_lossgrad_chain")
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r03_bench_pmc_traffic.json")
+NET_SEED = 20241004         # seed of the depth network's random initialisation (there are no pretrained weights on the GPU box)
+
+
+def source_stamp():
+    """sha256 over the sources that decide which kernels a refinement step launches and with what arguments (csrc/*, the launch plan).
+    tools/bench_pmc.sh stores it next to the PMC traffic it measures; a mismatch means the committed traffic figure is stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "end-to-end-self-supervised-slam_amd")
+    files = sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.h")))
+    files += [os.path.join(pkg, "e2ehip", f) for f in ("netplan.py", "stepplan.py", "fusionmap.py", "ops.py")]
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def parse_args(argv=None):
@@ -52,6 +69,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel event-timing pass")
     ap.add_argument("--dry", action="store_true", help="CPU rehearsal of the multi-process path (gloo, no GPU, no kernels): launch / exchange / gather only")
+    ap.add_argument("--print-stamp", action="store_true", help="print source_stamp() and exit (tools/bench_pmc.sh)")
+    ap.add_argument("--same-sequence", action="store_true", help="[N > 1] every rank refines the SAME sequence (seed 1234): the averaged update must then "
+                                                                 "equal the one-rank update -- a correctness check of the gradient exchange, not a benchmark")
     # round-1 kernel-only workload
     ap.add_argument("--batch", type=int, default=1, help="[warp] keyframe pairs per launch (reference: 1)")
     ap.add_argument("--no-graph", action="store_true", help="[warp] eager launches instead of hipGraph replay")
@@ -147,10 +167,11 @@ def seq_bench(a, rank, world, dev):
     cfg.DATA.name = "TUM" if a.tum else "ICL"
     cfg.DEMO.frame_threshold = 0.12 if a.tum else 0.05             # README.md:157 of the reference
     step_m = 0.13 if a.tum else 0.06                               # camera step of the synthetic orbit: every frame is a keyframe
-    seq = make_sequence(L, H, W, seed=1234 + rank, step=step_m, K=tum_intrinsics(H, W) if a.tum else None, holes=0.1 if a.tum else 0.0,
+    seq = make_sequence(L, H, W, seed=1234 + (0 if a.same_sequence else rank), step=step_m, K=tum_intrinsics(H, W) if a.tum else None, holes=0.1 if a.tum else 0.0,
                         scene="corner" if a.odom != "gt" else "plane")
     K = a.steps if a.steps is not None else spk * (L - 1)
     Wm = a.warmup if a.warmup is not None else 6
+    torch.manual_seed(NET_SEED)                         # the network initialisation is part of the workload: map size (KNN / association cost) follows it
     with contextlib.redirect_stdout(sys.stderr):        # the driver mirrors the reference's start-up prints; stdout carries ONE JSON line
         slam = SLAM(cfg, sequence=seq)
     slam.set_refinement_mode()
@@ -158,7 +179,7 @@ def seq_bench(a, rank, world, dev):
     sched = slam.keyframe_schedule()
     if world > 1:
         slam.optimizer.prebuild(slam.models["depth"].used_parameters())
-    state = {"i": 0, "passes": 0}
+    state = {"i": 0, "passes": 0, "visited": []}
 
     def run_steps(n):                                   # EXACTLY n refinement steps, continuing along the keyframe schedule
         while n > 0:
@@ -166,6 +187,8 @@ def seq_bench(a, rank, world, dev):
                 slam.reset_map()
                 state["i"], state["passes"] = 0, state["passes"] + 1
             k = min(spk, n)
+            state["visited"].append((state["passes"], state["i"], slam.map.count[0:1].clone()))    # (pass, keyframe, map size before the keyframe:
+                                                                                                 #  a device-side copy, read after the timed region)
             nxt = sched[state["i"] + 1] if state["i"] + 1 < len(sched) else None
             slam.refinement(*sched[state["i"]], max_steps=k, next_pair=nxt)
             slam.first_iter = False
@@ -181,12 +204,19 @@ def seq_bench(a, rank, world, dev):
     run_steps(Wm)
     barrier()
     done0 = slam.refinement_steps_done
+    v0 = len(state["visited"])
     t0 = time.perf_counter()
     run_steps(K)
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
     barrier()
     assert slam.refinement_steps_done - done0 == K
+    timed = state["visited"][v0:]
+    covered = {"first": {"pass": timed[0][0], "keyframe": timed[0][1] + 1, "map_points_before": int(timed[0][2])},
+               "last": {"pass": timed[-1][0], "keyframe": timed[-1][1] + 1, "map_points_before": int(timed[-1][2])},
+               "keyframes_in_timed_region": len(timed), "of_keyframes_per_pass": len(sched),
+               "note": "keyframe k = k-th pair of the schedule (1-based); KNN / association cost grows with the map, so a short timed region "
+                       "that starts at keyframe 3 reads faster than a whole pass (profiles/r03_bench_seq_fullpass.json = --steps 177)"}
     if world > 1:
         tt = torch.tensor([el], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -200,7 +230,7 @@ def seq_bench(a, rank, world, dev):
         dist.all_gather(allcs, cs)
         replicas_identical = all(float(c) == float(allcs[0]) for c in allcs)
         if not replicas_identical:
-            print(f"WARNING: ranks disagree about the network parameters: {[float(c) for c in allcs]}", file=sys.stderr)
+            print(f"ERROR: ranks disagree about the network parameters: {[float(c) for c in allcs]}", file=sys.stderr)
 
     # ---- per-kernel durations of ONE more keyframe, measured live with HIP events on the launch streams --------------
     roof = {}
@@ -219,30 +249,55 @@ def seq_bench(a, rank, world, dev):
             tf = conv_fl / (conv_ms * 1e-3) / 1e12
             # HBM-side bytes per C-ABI convolution call from the committed PMC passes of this same workload (tools/bench_pmc.sh; counters
             # cannot be read live): bytes of all conv-family kernels per refinement step x steps per keyframe / calls per keyframe
-            traffic, pmc = None, os.path.join(ROOT, "profiles", "r02_bench_pmc_traffic.json")
+            traffic, traffic_note, pmc = None, "no PMC record", PMC_TRAFFIC
             if os.path.isfile(pmc):
                 with open(pmc) as f:
                     t = json.load(f)
-                traffic = t["conv_gemm_family_bytes_total"] / t["refinement_steps"] * spk / max(conv_calls, 1)
+                if t.get("source_stamp") == source_stamp():
+                    traffic = t["conv_gemm_family_bytes_total"] / t["refinement_steps"] * spk / max(conv_calls, 1)
+                    traffic_note = (f"bytes per C-ABI convolution call from {os.path.relpath(pmc, ROOT)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                    f"this workload over {t['refinement_steps']} steps, taken at source stamp {t['source_stamp']} = this build)")
+                else:
+                    traffic_note = f"{os.path.relpath(pmc, ROOT)} was taken at source stamp {t.get('source_stamp')}, this build is {source_stamp()}: stale, not reported"
             roof["roofline"] = {
                 "bound": "mfma", "kernel": "depth-network convolution GEMMs (k_conv_gemm forward / backward-data, k_wgrad_gemm* backward-weight incl. their "
                                            "split-K / slab reductions), fp32 v_mfma_f32_32x32x2_f32",
                 "achieved": tf, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFS, "traffic": traffic,
-                "sustained_peak_note": "pure fp32-MFMA launches of GEMM shape sustain 124-126 TFLOP/s on this part (scratch/mfma_grid.hip, "
-                                       "profiles/r02_mfma_grid_microbench.txt); frac uses the nominal 157.3",
-                "traffic_note": "bytes per C-ABI convolution call (a call = GEMM + its split-K / slab reduction), profiles/r02_bench_pmc_traffic.json",
+                "traffic_note": traffic_note,
                 "launches": conv_calls, "avg_launch_us": 1e3 * conv_ms / max(conv_calls, 1), "algorithmic_gflop_per_keyframe": conv_fl / 1e9,
                 "ms_per_keyframe": conv_ms, "share_of_event_timed_kernel_time": conv_ms / all_ms,
                 "by_entry_point": {n: {"calls": rows[n]["calls"], "ms": round(rows[n]["ms"], 4), "tflops": rows[n]["flops"] / (rows[n]["ms"] * 1e-3) / 1e12}
                                    for n in CONV_ENTRY_POINTS if n in rows},
                 "method": "HIP events around every C-ABI call of one keyframe (3 steps + map update) after the timed region, on the stream each call runs on, "
                           "backward-weight overlap off; ~2 us of event overhead per call is included"}
-        if warp:
-            wms, wby, wc = sum(r["ms"] for r in warp), sum(r["bytes"] for r in warp), sum(r["calls"] for r in warp)
+        if warp and slam.step_plan is not None:
+            # the fused loss kernel alone: 20 back-to-back launches on the step's own resident buffers inside ONE captured graph between ONE
+            # event pair (an event pair per launch adds ~6 us to a ~10 us kernel; rocprofv3's per-kernel average agrees with this figure)
+            wby, RUN, lp = warp[0]["bytes"] // max(warp[0]["calls"], 1), 20, slam.step_plan.loss
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                lp.step()
+                side.synchronize()
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk, stream=side):
+                    for _ in range(RUN):
+                        lp.step()
+                ts = []
+                for _ in range(30):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(side)
+                    gk.replay()
+                    e1.record(side)
+                    side.synchronize()
+                    ts.append(e0.elapsed_time(e1) / RUN)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            ts.sort()
+            wms = sum(ts[5:-5]) / len(ts[5:-5])
             gbs = wby / (wms * 1e-3) / 1e9
-            roof["roofline_warp"] = {"bound": "hbm", "kernel": "k_warp_photo_lossgrad", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": gbs / HBM_PEAK_GBS, "traffic": None, "launches": wc, "avg_launch_us": 1e3 * wms / wc,
-                                     "algorithmic_bytes_per_launch": wby // wc}
+            roof["roofline_warp"] = {"bound": "hbm", "kernel": "k_warp_photo_lossgrad (+ its loss finalisation)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": 1e3 * wms, "algorithmic_bytes_per_launch": wby,
+                                     "method": f"{RUN} back-to-back launches per captured graph between one event pair, trimmed mean of 30 replays"}
         roof["kernel_time_ms_per_keyframe"] = {n: round(r["ms"], 4) for n, r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:16]}
 
     # ---- end of run: per-rank map sizes and the map gather (outside the timed region) ---------------------------------
@@ -263,7 +318,12 @@ def seq_bench(a, rank, world, dev):
                                       + (", one sequence per GPU, 1 all-reduce of the 57.3 MB gradient bucket per step" if world > 1 else ""),
                           "height": H, "width": W, "seq_len": L, "keyframes_per_pass": len(sched), "refinement_steps_per_keyframe": spk, "odom": a.odom,
                           "sequence_passes_started": state["passes"] + 1, "map_points_rank0": map_points, "map_points_per_rank": sizes,
-                          "map_points_gathered": gathered, "ate_m": ate, "replicas_identical": replicas_identical}}
+                          "map_points_gathered": gathered, "ate_m": ate, "replicas_identical": replicas_identical, "keyframes_covered": covered,
+                          "network_seed": NET_SEED, "parameter_checksum": float(slam.optimizer.flat.data.double().sum()) if slam.optimizer.flat is not None else None,
+                          "same_sequence_on_every_rank": bool(a.same_sequence)}}
+        if not replicas_identical:                      # a data-parallel run whose replicas diverged measured nothing
+            out["value"] = None
+            out["error"] = "replicas diverged: parameter checksums differ between ranks"
         out.update(roof)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_seq(H, W, a.tum)
@@ -271,6 +331,8 @@ def seq_bench(a, rank, world, dev):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if not replicas_identical:
+        sys.exit(3)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -409,6 +471,9 @@ def warp_bench(a, rank, world, dev):
 
 def main():
     a = parse_args()
+    if a.print_stamp:
+        print(source_stamp())
+        return
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))

@@ -129,8 +129,11 @@ __global__ void k_grid_init(GridInfo* gi, unsigned int* counts, unsigned int* fi
 // NOTE: device-scope atomics that hit ONE address serialise at the memory side at ~0.18 us each (3072 of them made
 // this kernel 555 us): the workgroups publish their partial boxes instead and k_grid_setup folds them.
 #define BBOX_BLOCKS 256
-__global__ __launch_bounds__(KT) void k_grid_bbox(const float* __restrict__ p, int64_t n, unsigned int* __restrict__ part) {
+// `nptr` (every build kernel): when not NULL the number of reference points is read from DEVICE memory (a resident map whose size the
+// host never learns: e2e_knn1_index_build_dev); grids are then sized by the capacity and the loops stop at *nptr
+__global__ __launch_bounds__(KT) void k_grid_bbox(const float* __restrict__ p, int64_t n, const long long* __restrict__ nptr, unsigned int* __restrict__ part) {
     __shared__ unsigned int slo[3][KT / 64], shi[3][KT / 64];
+    if (nptr) n = (int64_t)*nptr;
     unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
     for (int64_t i = (int64_t)blockIdx.x * KT + threadIdx.x; i < n; i += (int64_t)gridDim.x * KT)
 #pragma unroll
@@ -158,8 +161,10 @@ __global__ __launch_bounds__(KT) void k_grid_bbox(const float* __restrict__ p, i
     }
 }
 
-__global__ __launch_bounds__(BBOX_BLOCKS) void k_grid_setup(GridInfo* gi, const unsigned int* __restrict__ part, int nparts, int gmax) {
+__global__ __launch_bounds__(BBOX_BLOCKS) void k_grid_setup(GridInfo* gi, const unsigned int* __restrict__ part, int nparts, int gmax,
+                                                            const long long* __restrict__ nptr) {
     __shared__ unsigned int sh[6][BBOX_BLOCKS / 64];
+    if (nptr) gmax = (*nptr >= GRID_BIG_N2) ? GRID_MAX_BIG : GRID_MAX_SMALL;      // the host's rule (grid_max_for) on the device-resident count
     for (int c = 0; c < 6; ++c) {
         unsigned int v = (threadIdx.x < nparts) ? part[threadIdx.x * 6 + c] : (c < 3 ? 0xFFFFFFFFu : 0u);
 #pragma unroll
@@ -198,8 +203,9 @@ __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int dim
     return min(max((int)floorf((v - o) * inv_h), 0), dim - 1);
 }
 
-__global__ __launch_bounds__(KT) void k_grid_count(const float* __restrict__ p, int64_t n, const GridInfo* __restrict__ gi,
+__global__ __launch_bounds__(KT) void k_grid_count(const float* __restrict__ p, int64_t n, const long long* __restrict__ nptr, const GridInfo* __restrict__ gi,
                                                    unsigned int* __restrict__ cell_of, unsigned int* __restrict__ counts) {
+    if (nptr) n = (int64_t)*nptr;
     const float ox = gi->origin[0], oy = gi->origin[1], oz = gi->origin[2], ih = gi->inv_h;
     const int dx = gi->dims[0], dy = gi->dims[1], dz = gi->dims[2];
     for (int64_t i = (int64_t)blockIdx.x * KT + threadIdx.x; i < n; i += (int64_t)gridDim.x * KT) {
@@ -273,9 +279,10 @@ __global__ __launch_bounds__(KT) void k_scan_apply(const unsigned int* __restric
     }
 }
 
-__global__ __launch_bounds__(KT) void k_grid_scatter(const float* __restrict__ p, int64_t n, const unsigned int* __restrict__ cell_of,
+__global__ __launch_bounds__(KT) void k_grid_scatter(const float* __restrict__ p, int64_t n, const long long* __restrict__ nptr, const unsigned int* __restrict__ cell_of,
                                                      const unsigned int* __restrict__ starts, unsigned int* __restrict__ fill,
                                                      float4* __restrict__ sorted) {
+    if (nptr) n = (int64_t)*nptr;
     for (int64_t i = (int64_t)blockIdx.x * KT + threadIdx.x; i < n; i += (int64_t)gridDim.x * KT) {
         const unsigned int c = cell_of[i];
         const unsigned int pos = starts[c] + atomicAdd(&fill[c], 1u);
@@ -485,8 +492,8 @@ extern "C" {
 static int knn1_brute(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists, long long* idx, void* workspace, hipStream_t st);
 #define KNN_GRID_MIN_N2 8192      // below this the brute force is already cheap
 
-static int64_t grid_ws_bytes(int64_t n1, int64_t n2) {
-    const int64_t nc = grid_cells_cap(n2), nb = (nc + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
+static int64_t grid_ws_bytes(int64_t n1, int64_t n2, bool big_always = false) {
+    const int64_t nc = big_always ? (int64_t)GRID_MAX_BIG * GRID_MAX_BIG * GRID_MAX_BIG : grid_cells_cap(n2), nb = (nc + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
     // GridInfo | counts[nc+1] | starts[nc+1] | fill[nc] | bsum[nb] | cell_of[n2] | unresolved[n1] | sorted float4[n2]
     return 256 + 4 * (nc + 1) * 2 + 4 * nc + 4 * (nb + 1) + 4 * 6 * BBOX_BLOCKS + 4 * n2 + 4 * n1 + 64 + 16 * n2;
 }
@@ -507,9 +514,9 @@ struct GridWs {
 };
 
 // carve the workspace: `nq` = number of query slots reserved for the unresolved list
-static GridWs grid_ws(void* workspace, int64_t nq, int64_t n2) {
+static GridWs grid_ws(void* workspace, int64_t nq, int64_t n2, bool big_always = false) {
     GridWs g;
-    g.nc = grid_cells_cap(n2);
+    g.nc = big_always ? (int64_t)GRID_MAX_BIG * GRID_MAX_BIG * GRID_MAX_BIG : grid_cells_cap(n2);
     g.nb = (int)((g.nc + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK);
     char* w = (char*)workspace;
     g.gi = (GridInfo*)w; w += 256;
@@ -527,18 +534,19 @@ static GridWs grid_ws(void* workspace, int64_t nq, int64_t n2) {
 
 __global__ void k_grid_reset_unresolved(GridInfo* gi) { gi->n_unresolved = 0; }
 
-static void grid_build(const float* p2, int64_t n2, const GridWs& g, hipStream_t st) {
+// n2: number of reference points, or -- with n2_dev != NULL -- their CAPACITY (the live count is read on the device)
+static void grid_build(const float* p2, int64_t n2, const long long* n2_dev, const GridWs& g, hipStream_t st) {
     const int64_t nscan = g.nc + 1;
     const int gp = (int)((n2 + KT - 1) / KT > 2048 ? 2048 : (n2 + KT - 1) / KT);
     hipLaunchKernelGGL(k_grid_init, dim3(2048), dim3(256), 0, st, g.gi, g.counts, g.fill, g.nc);
     const int bb_blocks = gp > BBOX_BLOCKS ? BBOX_BLOCKS : gp;
-    hipLaunchKernelGGL(k_grid_bbox, dim3(bb_blocks), dim3(KT), 0, st, p2, n2, g.bbpart);
-    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(BBOX_BLOCKS), 0, st, g.gi, g.bbpart, bb_blocks, grid_max_for(n2));
-    hipLaunchKernelGGL(k_grid_count, dim3(gp), dim3(KT), 0, st, p2, n2, g.gi, g.cell_of, g.counts);
+    hipLaunchKernelGGL(k_grid_bbox, dim3(bb_blocks), dim3(KT), 0, st, p2, n2, n2_dev, g.bbpart);
+    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(BBOX_BLOCKS), 0, st, g.gi, g.bbpart, bb_blocks, grid_max_for(n2), n2_dev);
+    hipLaunchKernelGGL(k_grid_count, dim3(gp), dim3(KT), 0, st, p2, n2, n2_dev, g.gi, g.cell_of, g.counts);
     hipLaunchKernelGGL(k_scan_blocksum, dim3(g.nb), dim3(KT), 0, st, g.counts, nscan, g.bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, g.bsum, g.nb);
     hipLaunchKernelGGL(k_scan_apply, dim3(g.nb), dim3(KT), 0, st, g.counts, nscan, g.bsum, g.starts);
-    hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(KT), 0, st, p2, n2, g.cell_of, g.starts, g.fill, g.sorted);
+    hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(KT), 0, st, p2, n2, n2_dev, g.cell_of, g.starts, g.fill, g.sorted);
 }
 
 static void grid_query(const float* p1, int64_t n1, const GridWs& g, float* dists, long long* idx, hipStream_t st) {
@@ -548,7 +556,7 @@ static void grid_query(const float* p1, int64_t n1, const GridWs& g, float* dist
 
 static int knn1_grid(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists, long long* idx, void* workspace, hipStream_t st) {
     const GridWs g = grid_ws(workspace, n1, n2);
-    grid_build(p2, n2, g, st);
+    grid_build(p2, n2, nullptr, g, st);
     grid_query(p1, n1, g, dists, idx, st);
     return E2E_OK;
 }
@@ -557,8 +565,35 @@ static int knn1_grid(const float* p1, int64_t n1, const float* p2, int64_t n2, f
  * keyframe).  The index occupies e2e_knn1_workspace_bytes(max_queries, n2) bytes owned by the caller. */
 int e2e_knn1_index_build(const float* p2, int64_t n2, int64_t max_queries, void* index, void* stream) {
     E2E_REQUIRE(p2 && index && n2 > 0 && n2 < 0xFFFFFFFFll && max_queries > 0 && max_queries < 0xFFFFFFFFll, E2E_ERR_ARG, "e2e_knn1_index_build: bad argument");
-    grid_build(p2, n2, grid_ws(index, max_queries, n2), (hipStream_t)stream);
+    grid_build(p2, n2, nullptr, grid_ws(index, max_queries, n2), (hipStream_t)stream);
     E2E_LAUNCH_CHECK("e2e_knn1_index_build");
+    return E2E_OK;
+}
+
+/* The same index over a RESIDENT reference set whose live size lives in device memory (*n2_dev <= n2_capacity, > 0): the host never
+ * reads it, every launch argument is constant from one build to the next (capturable into a hipGraph), grids are sized by the
+ * capacity.  The index occupies e2e_knn1_index_capacity_bytes(max_queries, n2_capacity) bytes; query it with
+ * e2e_knn1_index_query_dev.  Results are those of e2e_knn1_index_build / _query on the first *n2_dev points. */
+int64_t e2e_knn1_index_capacity_bytes(int64_t max_queries, int64_t n2_capacity) {
+    if (max_queries <= 0 || n2_capacity <= 0) return 0;
+    return grid_ws_bytes(max_queries, n2_capacity, true);
+}
+
+int e2e_knn1_index_build_dev(const float* p2, const long long* n2_dev, int64_t n2_capacity, int64_t max_queries, void* index, void* stream) {
+    E2E_REQUIRE(p2 && n2_dev && index && n2_capacity > 0 && n2_capacity < 0xFFFFFFFFll && max_queries > 0 && max_queries < 0xFFFFFFFFll, E2E_ERR_ARG,
+                "e2e_knn1_index_build_dev: bad argument");
+    grid_build(p2, n2_capacity, n2_dev, grid_ws(index, max_queries, n2_capacity, true), (hipStream_t)stream);
+    E2E_LAUNCH_CHECK("e2e_knn1_index_build_dev");
+    return E2E_OK;
+}
+
+int e2e_knn1_index_query_dev(const float* p1, int64_t n1, int64_t n2_capacity, int64_t max_queries, void* index, float* dists, long long* idx, void* stream) {
+    E2E_REQUIRE(p1 && index && dists && idx && n1 > 0 && n1 <= max_queries && n2_capacity > 0, E2E_ERR_ARG,
+                "e2e_knn1_index_query_dev: bad argument (n1=%lld must not exceed the max_queries=%lld the index was built for)", (long long)n1, (long long)max_queries);
+    const GridWs g = grid_ws(index, max_queries, n2_capacity, true);
+    hipLaunchKernelGGL(k_grid_reset_unresolved, dim3(1), dim3(1), 0, (hipStream_t)stream, g.gi);
+    grid_query(p1, n1, g, dists, idx, (hipStream_t)stream);
+    E2E_LAUNCH_CHECK("e2e_knn1_index_query_dev");
     return E2E_OK;
 }
 

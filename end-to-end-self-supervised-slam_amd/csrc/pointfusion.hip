@@ -194,7 +194,8 @@ __global__ __launch_bounds__(PF_T) void k_pf_assoc1(const float* __restrict__ pt
                                                     const float* __restrict__ Ng, float dist_th, float dot_th,
                                                     float u_hi, float v_hi, unsigned int* __restrict__ pix_out,
                                                     unsigned char* __restrict__ flags,
-                                                    unsigned long long* __restrict__ pix_key, int H, int W) {
+                                                    unsigned long long* __restrict__ pix_key, int H, int W, const long long* __restrict__ Mp) {
+    if (Mp) M = (int64_t)*Mp;                         // resident map: the live size is device data (e2e_pf_associate_dev)
     const float fx = K[0], fy = K[5], cx = K[2], cy = K[6];
     const Pose Ti = inverse_pose(load_pose(pose));
     for (int64_t n = (int64_t)blockIdx.x * PF_T + threadIdx.x; n < M; n += (int64_t)gridDim.x * PF_T) {
@@ -237,7 +238,9 @@ __global__ __launch_bounds__(PF_T) void k_pf_assoc2(const float* __restrict__ pt
                                                     const float* __restrict__ Vg, const unsigned int* __restrict__ pix_in,
                                                     const unsigned char* __restrict__ flags,
                                                     const unsigned long long* __restrict__ pix_key,
-                                                    unsigned int* __restrict__ pix_best, unsigned int* __restrict__ any_match) {
+                                                    unsigned int* __restrict__ pix_best, unsigned int* __restrict__ any_match,
+                                                    const long long* __restrict__ Mp) {
+    if (Mp) M = (int64_t)*Mp;
     for (int64_t n = (int64_t)blockIdx.x * PF_T + threadIdx.x; n < M; n += (int64_t)gridDim.x * PF_T) {
         if (flags[n] != 3) continue;
         const unsigned int q = pix_in[n];
@@ -260,9 +263,10 @@ __global__ __launch_bounds__(PF_T) void k_pf_fuse(float* __restrict__ pts, float
                                                   const unsigned char* __restrict__ flags, const unsigned int* __restrict__ pix_best,
                                                   const float* __restrict__ Vg, const float* __restrict__ Ng,
                                                   const float* __restrict__ rgb, const float* __restrict__ alpha,
-                                                  const unsigned int* __restrict__ any_match) {
+                                                  const unsigned int* __restrict__ any_match, const long long* __restrict__ Mp) {
     // gradslam fuses only `if has_points and correspondences exist`; otherwise the map is left untouched
     if (*any_match == 0u) return;
+    if (Mp) M = (int64_t)*Mp;
     for (int64_t n = (int64_t)blockIdx.x * PF_T + threadIdx.x; n < M; n += (int64_t)gridDim.x * PF_T) {
         float a = 0.f, fp[3] = {0.f, 0.f, 0.f}, fn[3] = {0.f, 0.f, 0.f}, fc[3] = {0.f, 0.f, 0.f};
         if (flags[n] == 3) {
@@ -327,7 +331,8 @@ __global__ __launch_bounds__(PF_T) void k_cp_count(int64_t total, const unsigned
 
 // exclusive scan of nb block counts in place; total -> *total_out (int64).  One workgroup.
 __global__ __launch_bounds__(1024) void k_scan_counts(unsigned int* __restrict__ counts, int nb, long long* __restrict__ total_out,
-                                                      long long add_to_total) {
+                                                      long long add_to_total, const long long* __restrict__ add_dev) {
+    if (add_dev) add_to_total = *add_dev;             // (every thread reads it before thread 0 may overwrite *total_out == *add_dev: barriers below)
     __shared__ unsigned int wsum[16];
     __shared__ unsigned int carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -426,8 +431,9 @@ __global__ __launch_bounds__(PF_T) void k_pf_append(int64_t N, int64_t M, const 
                                                     const float* __restrict__ Vg, const float* __restrict__ Ng,
                                                     const float* __restrict__ rgb, const float* __restrict__ alpha,
                                                     float* __restrict__ pts, float* __restrict__ nrm, float* __restrict__ col,
-                                                    float* __restrict__ cc, int64_t cap) {
+                                                    float* __restrict__ cc, int64_t cap, const long long* __restrict__ Mp) {
     __shared__ unsigned int sh[PF_T / 64];
+    if (Mp) M = (int64_t)*Mp;
     const int64_t base = (int64_t)blockIdx.x * CP_BLOCK + (int64_t)threadIdx.x * CP_ITEMS;
     bool pr[CP_ITEMS];
     unsigned int c = 0;
@@ -549,11 +555,35 @@ int e2e_pf_associate(const float* map_points, const float* map_normals, const fl
         // thresholds evaluated in double then rounded to fp32, as the oracle's tensor-vs-python-float comparisons do
         const float u_hi = (float)((double)W - 0.999), v_hi = (float)((double)H - 0.999);
         hipLaunchKernelGGL(k_pf_assoc1, dim3(grid_for(M)), dim3(PF_T), 0, st, map_points, map_normals, map_ccounts, M, K, pose, Vg, Ng,
-                           dist_th, dot_th, u_hi, v_hi, w.pix_of_point, w.flags, w.pix_key, H, W);
+                           dist_th, dot_th, u_hi, v_hi, w.pix_of_point, w.flags, w.pix_key, H, W, (const long long*)nullptr);
         hipLaunchKernelGGL(k_pf_assoc2, dim3(grid_for(M)), dim3(PF_T), 0, st, map_points, map_ccounts, M, Vg, w.pix_of_point, w.flags,
-                           w.pix_key, w.pix_best, w.any_match);
+                           w.pix_key, w.pix_best, w.any_match, (const long long*)nullptr);
     }
     E2E_LAUNCH_CHECK("e2e_pf_associate");
+    return E2E_OK;
+}
+
+/* e2e_pf_associate on a RESIDENT map whose live size is device data: map_count_dev[0] = M (int64, 0 <= M <= map_capacity).  The
+ * host never reads it -- grids are sized by the capacity, every argument is constant from one keyframe to the next. */
+int e2e_pf_associate_dev(const float* map_points, const float* map_normals, const float* map_ccounts, const long long* map_count_dev,
+                         const float* K, const float* pose, const float* Vg, const float* Ng, float dist_th, float dot_th,
+                         void* workspace, int64_t map_capacity, int H, int W, void* stream) {
+    E2E_REQUIRE(map_capacity > 0 && map_capacity < (1ll << 32) - 1 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), E2E_ERR_ARG,
+                "e2e_pf_associate_dev: bad sizes cap=%lld", (long long)map_capacity);
+    E2E_REQUIRE(K && pose && Vg && Ng && workspace && map_points && map_normals && map_ccounts && map_count_dev, E2E_ERR_ARG,
+                "e2e_pf_associate_dev: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const PfWs w = pf_ws(workspace, map_capacity, H, W);
+    const int64_t N = (int64_t)H * W;
+    hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(N, 256, 1024)), dim3(256), 0, st, w.pix_key, N, PF_KEY_NONE);
+    hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(N, 256, 1024)), dim3(256), 0, st, w.pix_best, N, PF_NONE);
+    hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(64), 0, st, w.any_match, 4, 0u);
+    const float u_hi = (float)((double)W - 0.999), v_hi = (float)((double)H - 0.999);
+    hipLaunchKernelGGL(k_pf_assoc1, dim3(grid_for(map_capacity)), dim3(PF_T), 0, st, map_points, map_normals, map_ccounts, (int64_t)0, K, pose, Vg, Ng,
+                       dist_th, dot_th, u_hi, v_hi, w.pix_of_point, w.flags, w.pix_key, H, W, map_count_dev);
+    hipLaunchKernelGGL(k_pf_assoc2, dim3(grid_for(map_capacity)), dim3(PF_T), 0, st, map_points, map_ccounts, (int64_t)0, Vg, w.pix_of_point, w.flags,
+                       w.pix_key, w.pix_best, w.any_match, map_count_dev);
+    E2E_LAUNCH_CHECK("e2e_pf_associate_dev");
     return E2E_OK;
 }
 
@@ -567,20 +597,20 @@ int e2e_pf_table(int which, int64_t M, void* workspace, int64_t map_capacity, in
     if (which < 2) {
         const int nb = (int)((M + CP_BLOCK - 1) / CP_BLOCK);
         if (nb == 0) {
-            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, w.counts, 0, count_out, 0ll);
+            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, w.counts, 0, count_out, 0ll, (const long long*)nullptr);
         } else if (which == 0) {
             hipLaunchKernelGGL(k_cp_count<PRED_ACTIVE>, dim3(nb), dim3(PF_T), 0, st, M, w.flags, nullptr, nullptr, w.counts);
-            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, w.counts, nb, count_out, 0ll);
+            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, w.counts, nb, count_out, 0ll, (const long long*)nullptr);
             hipLaunchKernelGGL(k_cp_point_rows<PRED_ACTIVE>, dim3(nb), dim3(PF_T), 0, st, M, w.flags, w.pix_of_point, w.counts, W, rows);
         } else {
             hipLaunchKernelGGL(k_cp_count<PRED_SIMILAR>, dim3(nb), dim3(PF_T), 0, st, M, w.flags, nullptr, nullptr, w.counts);
-            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, w.counts, nb, count_out, 0ll);
+            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, w.counts, nb, count_out, 0ll, (const long long*)nullptr);
             hipLaunchKernelGGL(k_cp_point_rows<PRED_SIMILAR>, dim3(nb), dim3(PF_T), 0, st, M, w.flags, w.pix_of_point, w.counts, W, rows);
         }
     } else {
         const int nb = (int)((N + CP_BLOCK - 1) / CP_BLOCK);
         hipLaunchKernelGGL(k_cp_count<PRED_PIX_MATCHED>, dim3(nb), dim3(PF_T), 0, st, N, nullptr, w.pix_best, nullptr, w.counts);
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, w.counts, nb, count_out, 0ll);
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, w.counts, nb, count_out, 0ll, (const long long*)nullptr);
         hipLaunchKernelGGL(k_cp_pixel_rows, dim3(nb), dim3(PF_T), 0, st, N, w.pix_best, w.counts, W, rows);
     }
     E2E_LAUNCH_CHECK("e2e_pf_table");
@@ -598,13 +628,45 @@ int e2e_pf_fuse_append(float* map_points, float* map_normals, float* map_colors,
     const int64_t N = (int64_t)H * W;
     if (M > 0)
         hipLaunchKernelGGL(k_pf_fuse, dim3(grid_for(M)), dim3(PF_T), 0, st, map_points, map_normals, map_colors, map_ccounts, M,
-                           w.pix_of_point, w.flags, w.pix_best, Vg, Ng, rgb, alpha, w.any_match);
+                           w.pix_of_point, w.flags, w.pix_best, Vg, Ng, rgb, alpha, w.any_match, (const long long*)nullptr);
     const int nb = (int)((N + CP_BLOCK - 1) / CP_BLOCK);
     hipLaunchKernelGGL(k_cp_count<PRED_PIX_NEW>, dim3(nb), dim3(PF_T), 0, st, N, nullptr, w.pix_best, depth, w.counts);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, w.counts, nb, new_count_out, (long long)M);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, w.counts, nb, new_count_out, (long long)M, (const long long*)nullptr);
     hipLaunchKernelGGL(k_pf_append, dim3(nb), dim3(PF_T), 0, st, N, M, w.pix_best, depth, w.counts, Vg, Ng, rgb, alpha, map_points,
-                       map_normals, map_colors, map_ccounts, map_capacity);
+                       map_normals, map_colors, map_ccounts, map_capacity, (const long long*)nullptr);
     E2E_LAUNCH_CHECK("e2e_pf_fuse_append");
+    return E2E_OK;
+}
+
+// commit of a resident map step: count[0] = min(count[1], cap); an overflowing append (its points beyond `cap` were dropped by
+// k_pf_append) raises the sticky flag count[2], which the host reads once at the end of a pass
+__global__ void k_pf_commit(long long* count, long long cap) {
+    const long long m = count[1];
+    if (m > cap) count[2] = m;
+    count[0] = m > cap ? cap : m;
+}
+
+/* e2e_pf_fuse_append on a RESIDENT map: map_count_dev = int64[3] in device memory {M (in: live size, out: size after the append),
+ * scratch, sticky overflow flag (0, or the size an append would have needed when it exceeded map_capacity)}.  No host read-back:
+ * the caller checks map_count_dev[2] whenever it synchronises anyway. */
+int e2e_pf_fuse_append_dev(float* map_points, float* map_normals, float* map_colors, float* map_ccounts, long long* map_count_dev,
+                           int64_t map_capacity, const float* depth, const float* Vg, const float* Ng, const float* rgb,
+                           const float* alpha, void* workspace, int H, int W, void* stream) {
+    E2E_REQUIRE(map_capacity > 0 && H > 0 && W > 0, E2E_ERR_ARG, "e2e_pf_fuse_append_dev: bad sizes");
+    E2E_REQUIRE(map_points && map_normals && map_colors && map_ccounts && depth && Vg && Ng && rgb && alpha && workspace && map_count_dev,
+                E2E_ERR_ARG, "e2e_pf_fuse_append_dev: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const PfWs w = pf_ws(workspace, map_capacity, H, W);
+    const int64_t N = (int64_t)H * W;
+    hipLaunchKernelGGL(k_pf_fuse, dim3(grid_for(map_capacity)), dim3(PF_T), 0, st, map_points, map_normals, map_colors, map_ccounts, (int64_t)0,
+                       w.pix_of_point, w.flags, w.pix_best, Vg, Ng, rgb, alpha, w.any_match, (const long long*)map_count_dev);
+    const int nb = (int)((N + CP_BLOCK - 1) / CP_BLOCK);
+    hipLaunchKernelGGL(k_cp_count<PRED_PIX_NEW>, dim3(nb), dim3(PF_T), 0, st, N, nullptr, w.pix_best, depth, w.counts);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, w.counts, nb, map_count_dev + 1, 0ll, (const long long*)map_count_dev);
+    hipLaunchKernelGGL(k_pf_append, dim3(nb), dim3(PF_T), 0, st, N, (int64_t)0, w.pix_best, depth, w.counts, Vg, Ng, rgb, alpha, map_points,
+                       map_normals, map_colors, map_ccounts, map_capacity, (const long long*)map_count_dev);
+    hipLaunchKernelGGL(k_pf_commit, dim3(1), dim3(1), 0, st, map_count_dev, (long long)map_capacity);
+    E2E_LAUNCH_CHECK("e2e_pf_fuse_append_dev");
     return E2E_OK;
 }
 

@@ -360,9 +360,19 @@ class NetPlan:
         for op in reversed(self.ops[self.split_index:]):
             op.bwd(self, st)
         self.join()
+        # which gradient buffers hold a contribution at the hand-over point: the second half must start from exactly this state however
+        # often either half is executed (the data-parallel step runs each half once eagerly and once more under graph capture)
+        self._written_after_late = [op.out.written for op in self.ops]
 
     def backward_early_layers(self):
+        """Second part: layer3 ... stem.  The accumulate flags its launches take are those left by backward_late_layers(), restored here:
+        they are launch ARGUMENTS (frozen into a captured graph), so they must not depend on how many times this half ran before."""
         st = L.stream()
+        state = getattr(self, "_written_after_late", None)
+        if state is None:
+            raise RuntimeError("launch plan: backward_early_layers() follows backward_late_layers()")
+        for op, w in zip(self.ops, state):
+            op.out.written = w
         for op in reversed(self.ops[:self.split_index]):
             op.bwd(self, st)
         self.join()

@@ -392,6 +392,11 @@ class KnnIndex:
         self.ws = torch.empty(L.load().e2e_knn1_workspace_bytes(self.max_queries, self.n2), device=ref.device, dtype=torch.uint8)
         L.call("e2e_knn1_index_build", L.ptr(self.ref), self.n2, self.max_queries, L.ptr(self.ws), L.stream())
 
+    resident = False
+
+    def query(self, p1, n1, dists, idx, stream):
+        L.call("e2e_knn1_index_query", L.ptr(p1), int(n1), self.n2, self.max_queries, L.ptr(self.ws), L.ptr(dists), L.ptr(idx), stream)
+
 
 class _Knn1Indexed(torch.autograd.Function):
     @staticmethod
@@ -400,7 +405,7 @@ class _Knn1Indexed(torch.autograd.Function):
         n1 = a.shape[0]
         d = torch.empty(n1, device=a.device, dtype=torch.float32)
         idx = torch.empty(n1, device=a.device, dtype=torch.int64)
-        L.call("e2e_knn1_index_query", L.ptr(a), n1, index.n2, index.max_queries, L.ptr(index.ws), L.ptr(d), L.ptr(idx), L.stream())
+        index.query(a, n1, d, idx, L.stream())
         ctx.save_for_backward(a, index.ref, idx)
         ctx.mark_non_differentiable(idx)
         return d, idx
@@ -418,7 +423,7 @@ def knn1(p1, p2, algorithm="auto"):
     """p2 may be a KnnIndex (prebuilt grid over the reference cloud).  algorithm: "auto" | "brute" | "grid" (identical results).  K=1 nearest neighbour of every row of p1 (P1,3) among p2 (P2,3): (squared dists (P1,), idx (P1,) int64).
     Differentiable wrt p1 (d/dp1 = 2 g (p1 - p2[idx])); p2 is treated as data (the reference detaches it,
     online_adaption.py:643)."""
-    if isinstance(p2, KnnIndex):
+    if isinstance(p2, KnnIndex) or getattr(p2, "resident", False):       # a prebuilt index (e2ehip.fusionmap.ResidentKnnIndex over the map)
         if p1.dim() != 2 or p1.shape[1] != 3 or p1.shape[0] == 0:
             raise ValueError(f"p1: expected non-empty (P,3), got {tuple(p1.shape)}")
         if p1.shape[0] > p2.max_queries:

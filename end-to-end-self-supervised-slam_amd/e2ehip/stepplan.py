@@ -1,11 +1,11 @@
-"""One refinement step on a keyframe pair as THREE captured hipGraphs over resident buffers (online_adaption.py:274-318 of the
+"""One refinement step on a keyframe pair as TWO captured hipGraphs over resident buffers (online_adaption.py:274-318 of the
 reference: two depth-net forwards, median scaling, [3-D point loss], warp + photometric + regulariser, backward, Adam):
 
   graph A   depth network forward on the pair (e2ehip.netplan) + 1/disp + median ratio                 (e2e_depth_scale_fwd)
-  eager     3-D point loss against the global map, forward AND backward wrt the target depth: unproject -> rigid transform ->
-            exact nearest neighbour -> masked mean -> adjoints (7 launches; the map size is a launch argument that changes
-            with every keyframe, so this part is not captured)
-  graph B   fused warp + photometric + regulariser loss-and-gradient (e2e_warp_photo_lossgrad, device geometry), + the 3-D
+  graph B   3-D point loss against the global map, forward AND backward wrt the target depth: unproject -> rigid transform ->
+            exact nearest neighbour -> masked mean -> adjoints (7 launches; the map size is DEVICE data and the index one
+            resident buffer, so the launch arguments never change: e2ehip.fusionmap), fused warp + photometric + regulariser
+            loss-and-gradient (e2e_warp_photo_lossgrad, device geometry), + the 3-D
             gradient, median-chain backward, depth network backward (weight gradients straight into the flat bucket),
             [Adam + refresh of the GEMM weight layouts]
   (N > 1 GPUs: the all-reduce of the bucket runs eagerly between graph B and a third graph with Adam + the refresh)
@@ -119,14 +119,16 @@ class RefineStepPlan:
         L.call("e2e_vertex_normal_maps", L.ptr(d), L.ptr(self.K), L.ptr(self.pose_tgt), float(self.alpha_den), L.ptr(self.V), L.ptr(self.Nm), L.ptr(self.Vg),
                L.ptr(self.Ng), L.ptr(self.alpha), 1, self.H, self.W, st)
         L.call("e2e_transform_points", L.ptr(self.Vg), L.ptr(self.T), L.ptr(self.moved), N, 0, st)
-        L.call("e2e_knn1_index_query", L.ptr(self.moved), N, index.n2, index.max_queries, L.ptr(index.ws), L.ptr(self.nn_d), L.ptr(self.nn_idx), st)
+        index.query(self.moved, N, self.nn_d, self.nn_idx, st)
         L.call("e2e_masked_mean_lossgrad", L.ptr(self.nn_d), L.ptr(d), N, self.w_3d, L.ptr(self.l3), L.ptr(self.g_nn), L.ptr(self.ws_aux), st)
         L.call("e2e_knn1_bwd", L.ptr(self.g_nn), L.ptr(self.moved), L.ptr(index.ref), L.ptr(self.nn_idx), N, L.ptr(self.g_moved), st)
         L.call("e2e_transform_points", L.ptr(self.g_moved), L.ptr(self.T), L.ptr(self.g_cloud), N, 1, st)
         L.call("e2e_vertex_maps_bwd", L.ptr(d), L.ptr(self.K), L.ptr(self.pose_tgt), None, L.ptr(self.g_cloud), L.ptr(self.g3), 1, self.H, self.W, st)
 
-    def _backward(self, use_3d, with_adam, late_only=False):
+    def _backward(self, use_3d, with_adam, late_only=False, index=None):
         st = L.stream()
+        if index is not None:                                       # resident index: constant launch arguments, part of the captured graph
+            self._loss3d(index)
         self.loss.step()                                            # losses -> self.loss.loss[0..1]; d/d depth -> self.g_depth
         if use_3d:                                                  # g_depth_tgt += d(w_3d * l3)/d depth_tgt
             L.call("e2e_conv2d_act_bwd_acc", L.ptr(self.g3), L.ptr(self.g3), None, L.ptr(self.g_depth[1:2]), self.N, 1, 0, 1, st)
@@ -151,16 +153,21 @@ class RefineStepPlan:
         self._run("fwd", self._forward)
         if first_step and self.reg:
             self.init.copy_(self.delta)
-        if use_3d:
+        # the 3-D loss against a RESIDENT index (e2ehip.fusionmap: one buffer per run, map size on the device) has constant launch
+        # arguments and rides in the backward graph; any other index object is queried eagerly here
+        cap_idx, ikey = None, None
+        if use_3d and getattr(knn_index, "resident", False):
+            cap_idx, ikey = knn_index, knn_index.ws.data_ptr()
+        elif use_3d:
             self._loss3d(knn_index)
         if edist.world() == 1:
-            self._run(("bwd", use_3d, True), lambda: self._backward(use_3d, True))
+            self._run(("bwd", use_3d, True, ikey), lambda: self._backward(use_3d, True, index=cap_idx))
         else:
             # data-parallel: the exchange of the bucket's tail (head, decoder, layer4: 80 % of the bytes, complete after the first
             # part of the backward pass) travels while the early layers' backward computes; then the remaining 20 %, then Adam
             if self._split is None:
                 self._split = self.net.split_offset(self.opt.flat)
-            self._run(("bwd_late", use_3d), lambda: self._backward(use_3d, False, late_only=True))
+            self._run(("bwd_late", use_3d, ikey), lambda: self._backward(use_3d, False, late_only=True, index=cap_idx))
             handle = edist.exchange_gradients_late_(self.opt.flat, self._split, True)
             self._run("bwd_early", self.net.backward_early_layers)
             edist.exchange_gradients_early_(self.opt.flat, self._split, handle, True)

@@ -176,6 +176,7 @@ class SLAM:
                 self.idle_round()
         if self.args.DEBUG.print_metrics and self.mean_abs:
             print(torch.tensor(self.mean_abs).mean().item())
+        self.map.check_capacity()               # the one host read of the map size (and of its overflow flag) of the whole run
         if edist.world() > 1:                   # end of run: variable-length gather of the per-rank maps
             self.gathered_map = edist.gather_maps(*self.map.live())
         return self.map
@@ -201,7 +202,6 @@ class SLAM:
     def reset_map(self):
         """Start a new sequence pass with the current network: empty global map, first-keyframe rules apply again."""
         self.map.M = 0
-        self.map._knn = None
         self.first_iter = True
         self.estimated_poses = []
 
@@ -221,6 +221,13 @@ class SLAM:
                                             overlap=self.overlap_wgrad, use_graphs=self.use_graphs)
             self._inv_K = torch.pinverse(self.intrinsics[0, 0])
             self._poses_h = self.poses.detach().cpu()
+            # (prev, cur) -> relative transform pinv(P_prev) P_cur (training_utils.py:191-216) on the device: the whole keyframe schedule
+            # in ONE upload (poses are dataset inputs; a host-to-device copy per keyframe is a synchronisation point per keyframe)
+            sched = self.keyframe_schedule()
+            self._T_dev = {}
+            if sched:
+                Td = torch.stack([torch_poses_to_transforms(self._poses_h[:, [a, b]])[0, 1] for a, b in sched]).to(self.device)
+                self._T_dev = {pair: Td[i] for i, pair in enumerate(sched)}
             if edist.world() > 1:                   # one shared depth network: start from rank 0's parameters
                 edist.broadcast_parameters_(self.optimizer.flat)
                 self.step_plan.net.refresh_layouts()
@@ -229,8 +236,11 @@ class SLAM:
 
     def _load_pair(self, sp, prev, cur):
         """The keyframe pair's inputs into the plan's resident buffers (device-to-device copies + the ground-truth median)."""
-        # T = pinv(P_prev) P_cur (training_utils.py:191-216) on the host: poses are dataset inputs, 4x4 algebra
-        T = torch_poses_to_transforms(self._poses_h[:, [prev, cur]])[0, 1]
+        # T = pinv(P_prev) P_cur (training_utils.py:191-216) on the host: poses are dataset inputs, 4x4 algebra; uploaded once per pair
+        # (a pageable host-to-device copy inside the keyframe loop is a stream synchronisation point)
+        T = self._T_dev.get((prev, cur))
+        if T is None:
+            T = self._T_dev[(prev, cur)] = torch_poses_to_transforms(self._poses_h[:, [prev, cur]])[0, 1].to(self.device)
         sp.set_pair(self.colors[0, prev], self.colors[0, cur], self.gt_depths[0, prev], self.gt_depths[0, cur], self.intrinsics[0, 0], T, self.poses[0, cur],
                     inv_K=self._inv_K)
 
@@ -408,6 +418,12 @@ class SLAM:
     def _update_map(self, rgb_prev, rgb_cur, depth, pose_prev, pose_cur):
         """PointFusion map step(s) with the refined, median-scaled depths (2,1,H,W) of the pair (online_adaption.py:347-363)."""
         K = self.intrinsics[0, 0]
+        if self.args.MODEL.odom == "gt":
+            # resident form: map size, association tables and the appended rows never leave the device (no host read per keyframe)
+            if self.first_iter:
+                self.map.step_resident(rgb_prev, depth[0, 0], K, pose_prev)
+            self.map.step_resident(rgb_cur, depth[1, 0], K, pose_cur)
+            return self.map
         if self.first_iter:
             self.map.step(rgb_prev, depth[0, 0], K, pose_prev)
         live_pose = pose_cur

@@ -236,6 +236,22 @@ int e2e_pf_fuse_append(float* map_points, float* map_normals, float* map_colors,
                        const float* Ng, const float* rgb, const float* alpha, void* workspace, int H,
                        int W, long long* new_count_out, void* stream);
 
+/* The same two steps on a map whose live size is DEVICE data (online_adaption.py:347-363 keeps the global
+ * map on the device; gradslam reads its length on the host, which costs one synchronisation per keyframe).
+ * map_count_dev: int64[3] in device memory = {M, scratch, sticky overflow flag}; e2e_pf_associate_dev
+ * reads M, e2e_pf_fuse_append_dev reads M and writes the size after the append back to [0]
+ * (clamped to map_capacity; [2] then holds the size that would have been needed, else stays 0).
+ * Grids are sized by map_capacity, every argument is constant from keyframe to keyframe, the host reads
+ * nothing: results equal e2e_pf_associate / e2e_pf_fuse_append called with the same M. */
+int e2e_pf_associate_dev(const float* map_points, const float* map_normals, const float* map_ccounts,
+                         const long long* map_count_dev, const float* K, const float* pose, const float* Vg,
+                         const float* Ng, float dist_th, float dot_th, void* workspace, int64_t map_capacity,
+                         int H, int W, void* stream);
+int e2e_pf_fuse_append_dev(float* map_points, float* map_normals, float* map_colors, float* map_ccounts,
+                           long long* map_count_dev, int64_t map_capacity, const float* depth, const float* Vg,
+                           const float* Ng, const float* rgb, const float* alpha, void* workspace, int H, int W,
+                           void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* chamferdist.knn_points, K = 1, D = 3 (loss/losses.py:3,57)                                   */
 /* ------------------------------------------------------------------------------------------ */
@@ -258,6 +274,16 @@ int e2e_knn1_bwd(const float* g_dists, const float* p1, const float* p2, const l
 int e2e_knn1_index_build(const float* p2, int64_t n2, int64_t max_queries, void* index, void* stream);
 int e2e_knn1_index_query(const float* p1, int64_t n1, int64_t n2, int64_t max_queries, void* index,
                          float* dists, long long* idx, void* stream);
+/* The index over a RESIDENT reference set (the global map of online_adaption.py:638-645) whose live size
+ * is device data: *n2_dev points (0 < *n2_dev <= n2_capacity) are indexed, the host never reads the count.
+ * `index`: e2e_knn1_index_capacity_bytes(max_queries, n2_capacity) bytes, allocated once for the run;
+ * all launch arguments are constant between builds (the 3-D loss launches can sit in a captured hipGraph).
+ * Results are identical to e2e_knn1_fwd on the first *n2_dev points. */
+int64_t e2e_knn1_index_capacity_bytes(int64_t max_queries, int64_t n2_capacity);
+int e2e_knn1_index_build_dev(const float* p2, const long long* n2_dev, int64_t n2_capacity, int64_t max_queries,
+                             void* index, void* stream);
+int e2e_knn1_index_query_dev(const float* p1, int64_t n1, int64_t n2_capacity, int64_t max_queries, void* index,
+                             float* dists, long long* idx, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* disp -> depth, median scaling, regulariser, metrics, optimiser                                */

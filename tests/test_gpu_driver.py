@@ -261,3 +261,38 @@ def test_sparse_depth_supervision_runs():
         slam.main()
         logs.append(torch.stack(slam.log)[:, 0])
     assert torch.isfinite(logs[1]).all() and logs[1][0] > logs[0][0]
+
+
+def test_split_backward_graphs_reproduce_the_single_pass_gradient():
+    """The data-parallel form of a step runs the backward pass as TWO captured graphs (head / decoder / layer4, then layer3 ... stem,
+    e2ehip.stepplan.step) so that the first segment's all-reduce travels under the second.  Needs no torch.distributed: both halves go
+    through RefineStepPlan._run (eager execution + capture, then replays) for three steps with frozen weights, and the flat gradient
+    bucket must equal the one-pass backward bit for bit every time -- the accumulate flags of the early half are launch arguments
+    frozen into the graph and must not depend on how often either half ran before (round-2 defect: the capture pass saw the flags
+    the eager pass had left and recorded `accumulate = 1` for the first contribution to 12 gradient buffers)."""
+    from e2ehip.synthetic import make_sequence
+    from online_adaption import SLAM
+    H, W, L = 64, 96, 2
+    cfg = _cfg(H, W, L)
+    cfg.DEBUG.print_metrics = False
+    slam = SLAM(cfg, sequence=make_sequence(L, H, W, seed=5), state_dict=depthnet.random_state_dict(0))
+    slam.set_refinement_mode()
+    sp = slam._step_plan()
+    slam._load_pair(sp, 0, 1)
+    flat = slam.optimizer.flat
+    sp._run("fwd", sp._forward)
+    sp.init.copy_(sp.delta)
+    sp.use_graphs = False
+    flat.grad.zero_()
+    sp._backward(False, False)                          # reference: late + early layers in one eager pass, no Adam
+    torch.cuda.synchronize()
+    ref = flat.grad.clone()
+    assert float(ref.abs().sum()) > 0
+    sp.use_graphs = True
+    for it in range(3):                                 # it == 0: eager + capture; 1, 2: replays
+        flat.grad.zero_()
+        sp._run(("bwd_late", False), lambda: sp._backward(False, False, late_only=True))
+        sp._run("bwd_early", sp.net.backward_early_layers)
+        torch.cuda.synchronize()
+        assert torch.equal(flat.grad, ref), (it, float((flat.grad - ref).abs().max()))
+    assert ("bwd_late", False) in sp._graphs and "bwd_early" in sp._graphs

@@ -259,3 +259,37 @@ def test_knn_index_equals_one_shot_and_is_reusable():
         assert torch.equal(q.grad, qb.grad)
     with pytest.raises(ValueError):
         ops.knn1(torch.rand(9001, 3, device=DEV), index)
+
+
+def test_resident_map_step_and_index_equal_the_host_visible_forms():
+    """FusionMap.step_resident (live size on the device: e2e_pf_associate_dev / e2e_pf_fuse_append_dev, preallocated frame maps, no host
+    read) against FusionMap.step (host-visible size, itself checked against the oracle above): identical maps bit for bit over a 4-frame
+    chain; the resident nearest-neighbour index (one capacity-sized buffer rebuilt in place from the device-resident count,
+    e2e_knn1_index_build_dev) against the brute force after every frame; the sticky overflow flag."""
+    from e2ehip import ops
+    from e2ehip.fusionmap import FusionMap
+    H, W = 48, 64
+    K = _K(H, W).to(DEV)
+    a, b = FusionMap(6 * H * W, H, W, DEV), FusionMap(6 * H * W, H, W, DEV)
+    g = torch.Generator().manual_seed(9)
+    for f in range(4):
+        d, c = _scene(H, W, 30 + (f % 2))
+        pose = _pose(0.4 * f, 0.7 * f, 0.1 * f, (0.02 * f, 0.0, -0.01 * f)).to(DEV)
+        a.step(c.to(DEV), d.to(DEV), K, pose)
+        b.step_resident(c.to(DEV).contiguous(), d.to(DEV).contiguous(), K, pose)
+        assert b._M is None                              # nothing was read back
+        q = (torch.rand(3000, 3, generator=g) * 4 - 2).to(DEV)
+        index = b.knn_index(4096)                        # built from count[0] on the device
+        assert b._M is None
+        di, ii = ops.knn1(q, index)
+        assert b.M == a.M and b.M > 0
+        for x, y in zip(a.live(), b.live()):
+            assert torch.equal(x, y)
+        db, ib = ops.knn1(q, b.points[: b.M].contiguous(), "brute")
+        assert torch.equal(di, db) and torch.equal(ii, ib)
+    assert b.knn_index(4096) is index                    # one buffer for the run
+    small = FusionMap(int(a.M) // 3, H, W, DEV)
+    d, c = _scene(H, W, 30)
+    small.step_resident(c.to(DEV), d.to(DEV), K, _pose().to(DEV))
+    with pytest.raises(RuntimeError):
+        small.M

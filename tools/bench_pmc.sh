@@ -7,12 +7,14 @@ export TMPDIR=/tmp
 TAG=$1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/benchpmc_$TAG; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-ARGS="--no-cpu-baseline --no-roofline --steps 9 --warmup 3"
+STEPS=9; WARM=3
+ARGS="--no-cpu-baseline --no-roofline --steps $STEPS --warmup $WARM"
+STAMP=$(python3 bench.py --print-stamp)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/bp_f_$TAG -o pmc -- python3 bench.py $ARGS > $OUT/fetch.log 2>&1
 echo "fetch pass done" > $OUT/progress.txt
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/bp_w_$TAG -o pmc -- python3 bench.py $ARGS > $OUT/write.log 2>&1
 echo "write pass done" >> $OUT/progress.txt
-python3 - /tmp/bp_f_$TAG /tmp/bp_w_$TAG > $OUT/traffic.txt <<'PY'
+python3 - /tmp/bp_f_$TAG /tmp/bp_w_$TAG $((STEPS + WARM)) $STAMP > $OUT/traffic.txt <<'PY'
 import csv, glob, sys, collections, json
 def load(d, counter):
     fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
@@ -37,6 +39,8 @@ for k, n, f, fc, w in rows[:40]:
 conv = [r for r in rows if "k_conv_gemm" in r[0] or "_thin" in r[0] or "7x7" in r[0] or "k_wgrad_gemm" in r[0] or "k_wgrad_reduce" in r[0] or "k_conv_splitk" in r[0]]
 n = sum(r[1] for r in conv)
 tot = sum((r[3] + r[4]) * r[1] for r in conv)
-print(json.dumps({"refinement_steps": 12, "conv_gemm_family_kernel_launches": n, "conv_gemm_family_bytes_total": tot, "conv_gemm_family_bytes_per_kernel_launch": tot / max(n, 1)}))
+print(json.dumps({"refinement_steps": int(sys.argv[3]), "source_stamp": sys.argv[4], "conv_gemm_family_kernel_launches": n, "conv_gemm_family_bytes_total": tot, "conv_gemm_family_bytes_per_kernel_launch": tot / max(n, 1),
+                  "source": "tools/bench_pmc.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --no-cpu-baseline --no-roofline; FETCH_SIZE x2 for the 16-B-per-lane loaders (gfx950 correction), KiB -> bytes; L2 fabric-side requests, Infinity-Cache hits included"}))
 PY
+tail -1 $OUT/traffic.txt > $OUT/traffic.json
 cat $OUT/traffic.txt
