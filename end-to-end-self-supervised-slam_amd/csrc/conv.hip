@@ -108,12 +108,110 @@ __device__ __forceinline__ bool tap_coord(const ConvArgs& a, int yd, int xd, int
     }
 }
 
+// ---- direct epilogue of one 32x32 accumulator block (shared by k_conv_gemm and k_conv_gemm_sk) ---------------------------------
+// A lane holds column `col` and rows (r & 3) + 8 (r >> 2) of the block that starts at row `nb` (nb already includes the lane's
+// 4 * (lane >> 5)): the 16 rows sit at FIXED distances from the lane's first row, so every store / residual load is one buffer
+// instruction with the lane's byte offset in the VGPR and the row distance in the (wave-uniform) scalar offset -- no per-element
+// address arithmetic; rows past the end of the tensor get an out-of-range VGPR offset (one compare + select per element in the last
+// row tile; the hardware's range check does not include the scalar offset) and are dropped by the hardware.  The activation is
+// selected once, outside the element loops.  (The first version spent ~145 instructions per element here -- 64-bit row arithmetic,
+// bounds tests and a branch tree per element -- and every wave of a launch runs its epilogue at the same time, so none of it
+// overlapped with MFMA work: ~30 % of the kernel's cycles on the 64x64 layers.)
+struct EpiRsrc { __amdgpu_buffer_rsrc_t out, res, xin, pre; bool has_res; };
+
+template <bool TRANSPOSED>
+__device__ __forceinline__ EpiRsrc make_epi_rsrc(const ConvArgs& a) {
+    const int64_t out_elems = (int64_t)a.B * a.Hd * a.Wd * a.Ncols;
+    EpiRsrc e;
+    e.out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(out_elems * 4), 0x00020000);
+    e.res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, (int)(a.res ? out_elems * 4 : 0), 0x00020000);
+    e.has_res = a.res != nullptr;
+    e.xin = __builtin_amdgcn_make_buffer_rsrc((void*)((TRANSPOSED && a.xin) ? a.xin : a.out), 0, (int)((TRANSPOSED && a.xin) ? out_elems * 4 : 0), 0x00020000);
+    e.pre = __builtin_amdgcn_make_buffer_rsrc((void*)((TRANSPOSED && a.pre) ? a.pre : a.out), 0, (int)((TRANSPOSED && a.pre) ? out_elems * 4 : 0), 0x00020000);
+    return e;
+}
+
+template <bool TRANSPOSED>
+__device__ __forceinline__ void epilogue_block(const ConvArgs& a, const EpiRsrc& er, const f16v& acc, int col, int64_t nb, int64_t Ntot) {
+    constexpr unsigned OOB = 0x80000000u;
+    const bool col_ok = col < a.Ncols;
+    const float sc = (a.scale && col_ok) ? a.scale[col] : 1.f, sh = (a.shift && col_ok) ? a.shift[col] : 0.f;
+    const unsigned voff0 = (col_ok && nb < Ntot) ? (unsigned)((nb * a.Ncols + col) * 4) : OOB;
+    const int left = (int)((Ntot - nb < 32) ? Ntot - nb : 32);      // rows of this block that exist: the hardware's range check
+    unsigned vo[16];                                                // ignores the scalar offset, so rows past the end are masked here
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vo[r] = ((r & 3) + 8 * (r >> 2) < left) ? voff0 : OOB;
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[r], sc, sh);
+    if (TRANSPOSED && a.pre) {                      // a second gradient of the same tensor (residual branch)
+        float pp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            pp[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(er.pre, vo[r], ((r & 3) + 8 * (r >> 2)) * a.Ncols * 4, 0));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += pp[r];
+    }
+    if (TRANSPOSED && a.dact) {                     // x (act') of the tensor this gradient belongs to
+        float xx[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            xx[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(er.xin, vo[r], ((r & 3) + 8 * (r >> 2)) * a.Ncols * 4, 0));
+        if (a.dact == ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = xx[r] > 0.f ? v[r] : 0.f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = xx[r] > 0.f ? v[r] : v[r] * (xx[r] + 1.f);
+        }
+    }
+    if (er.has_res) {
+        float rr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            rr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(er.res, vo[r], ((r & 3) + 8 * (r >> 2)) * a.Ncols * 4, 0));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += rr[r];
+    }
+    if (a.act == ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+    } else if (a.act == ACT_ELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : expm1f(v[r]);
+    } else if (a.act == ACT_DISP) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = 10.f / (1.f + expf(-v[r])) + 0.01f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), er.out, vo[r], ((r & 3) + 8 * (r >> 2)) * a.Ncols * 4, 0);
+}
+
 // Thread -> A element mapping.  VEC == 4 (every layer but conv1): consecutive lanes fetch consecutive 16-byte channel
 // quads of ONE gathered pixel, so a wave-level load touches 64*16/(4*CB) rows x (4*CB contiguous bytes) -- full 128-byte
 // lines at CB = 32.  (The first version gave each lane its own row: 64 different lines per instruction, and the kernel
 // ran at the L1 request rate, not the MFMA rate: time did not react to chunk depth, read scheduling or warp
 // specialisation -- profiles/r01_notes.md.)  The LDS tile stays k-major for conflict-free MFMA operand reads; its row
 // stride is padded so that the transposing stores of 4*CB/16 lanes per row spread over banks.
+// XCD-aware workgroup order (MI355X: 8 XCDs, each with its own 4 MB L2; workgroups are dealt to them round-robin in launch order, so
+// consecutive ids land on DIFFERENT L2s).  Tiles that are neighbours in the image re-read each other's input rows (3x3 taps) and all
+// column tiles / K slices of one row tile read the same rows: this remap hands every XCD a CONTIGUOUS range of the launch's linear ids
+// (id -> start(id % 8) + id / 8), so those re-reads hit that XCD's L2 instead of the fabric (measured with in-kernel stamps, round 3:
+// a K chunk took 1.5 us per workgroup wherever fewer than three workgroups shared a CU -- the latency of ONE prefetched chunk of
+// fabric-served loads -- against 0.43 us of MFMA work).  Speed only: nothing depends on where a workgroup actually runs.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned id, unsigned n) {
+    const unsigned q = n >> 3, r = n & 7u, k = id & 7u, j = id >> 3;
+    return k * q + (k < r ? k : r) + j;
+}
+
+#ifdef E2E_CONV_STAMPS          // diagnostic build only (scratch/conv_stamps.py): s_memtime / s_memrealtime stamps of every workgroup's phases
+__device__ unsigned long long g_stamps[8192 * 8];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 template <int WM, int WN, int TM, int TN, int VEC, bool TRANSPOSED, int CB>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     constexpr int BM = 32 * WM * TM, BN = 32 * TN * WN, NT = 64 * WM * WN;
@@ -126,6 +224,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     static_assert(NT % KQ == 0 && NT % BM == 0, "tile / thread-count mismatch");
     __shared__ float As[2][CB][BM + APAD];
     __shared__ float Bs[2][CB][BN];
+    STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     // parity-class form (transposed gather, stride 2): this workgroup's class, its pixel sub-lattice and its tap subset
@@ -135,12 +234,22 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     const int kh0 = CLS ? ((py + a.off) & 1) : 0, kw0 = CLS ? ((px + a.off) & 1) : 0, kstep = CLS ? 2 : 1;
     const int nkh = CLS ? (a.KH - kh0 + 1) / 2 : a.KH, nkw = CLS ? (a.KW - kw0 + 1) / 2 : a.KW;
     const int64_t Ntot = (int64_t)a.B * Hc * Wc;
-    const int64_t n0 = (int64_t)(CLS ? (blockIdx.x >> 2) : blockIdx.x) * BM;
+    // non-class form: the launch's linear id -> XCD-contiguous order, decoded with (column tile, K slice) fastest and the row tile slowest
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (!CLS) {
+        const unsigned nyz = gridDim.y * gridDim.z;
+        const unsigned lin = xcd_contiguous(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * nyz);
+        bx = lin / nyz;
+        const unsigned rem = lin - bx * nyz;
+        bz = rem / gridDim.y;
+        by = rem - bz * gridDim.y;
+    }
+    const int64_t n0 = (int64_t)(CLS ? (bx >> 2) : bx) * BM;
     if (CLS && (n0 >= Ntot || nkh <= 0 || nkw <= 0)) return;        // classes are sized by the largest one; empty tap sets write nothing (output pre-zeroed by the host for KH < 2)
-    const int c0 = blockIdx.y * BN;
+    const int c0 = by * BN;
     const int K = CLS ? nkh * nkw * a.Cin : a.KH * a.KW * a.Cin;
     const int nchunks_all = (K + CB - 1) / CB;
-    const int cbeg = (a.ksplit > 1) ? blockIdx.z * a.cps : 0;
+    const int cbeg = (a.ksplit > 1) ? bz * a.cps : 0;
     const int cend = (a.ksplit > 1) ? min(nchunks_all, cbeg + a.cps) : nchunks_all;
     if (CLS && a.ksplit > 1 && cbeg >= nchunks_all) return;         // class form split by TAP: this class has fewer taps than slices (the
                                                                     // class epilogue only adds the slices that exist)
@@ -291,42 +400,49 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
 
     if (cbeg < cend) {
         load_chunk(cbeg);
+        STAMP(1);
         store_chunk(0);
     }
     __syncthreads();
+    STAMP(2);
     const int arow_l = wm * TM * 32 + (lane & 31), khalf = lane >> 5;
     for (int c = cbeg; c < cend; ++c) {
         const int buf = (c - cbeg) & 1;
         if (c + 1 < cend) load_chunk(c + 1);                // global loads in flight under the MFMAs below
+        // operand fragments of the WHOLE chunk are read into registers first, the MFMAs follow with counted LDS waits: hipcc's own
+        // schedule of the fused loop was read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs per k-pair on ONE register set, i.e. every pair of MFMAs
+        // waited for a fresh LDS round trip (~190 cycles per 128 cycles of matrix work: the kernels ran at half the MFMA rate with
+        // the pipe idle, round-3 disassembly)
+        constexpr int KH2 = (TM * TN == 1) ? CB / 2 : CB / 4;          // k-steps per register batch (2 x 2 blocks: two batches per chunk)
 #pragma unroll
-        for (int kk = 0; kk < CB / 2; ++kk) {
-            float av[TM], bv[TN];
+        for (int k0 = 0; k0 < CB / 2; k0 += KH2) {
+            float av[KH2][TM], bv[KH2][TN];
 #pragma unroll
-            for (int u = 0; u < TM; ++u) av[u] = As[buf][kk * 2 + khalf][arow_l + u * 32];
+            for (int kk = 0; kk < KH2; ++kk) {
 #pragma unroll
-            for (int t = 0; t < TN; ++t) bv[t] = Bs[buf][kk * 2 + khalf][(wn * TN + t) * 32 + (lane & 31)];
+                for (int u = 0; u < TM; ++u) av[kk][u] = As[buf][(k0 + kk) * 2 + khalf][arow_l + u * 32];
 #pragma unroll
-            for (int u = 0; u < TM; ++u)
+                for (int t = 0; t < TN; ++t) bv[kk][t] = Bs[buf][(k0 + kk) * 2 + khalf][(wn * TN + t) * 32 + (lane & 31)];
+            }
 #pragma unroll
-                for (int t = 0; t < TN; ++t) acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[t], acc[u][t], 0, 0, 0);
+            for (int kk = 0; kk < KH2; ++kk)
+#pragma unroll
+                for (int u = 0; u < TM; ++u)
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][u], bv[kk][t], acc[u][t], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, KH2 * (TM + TN) / 2, 0);     // all LDS reads of the batch (ds_read2: two values each) ...
+            __builtin_amdgcn_sched_group_barrier(0x008, KH2 * TM * TN, 0);           // ... ahead of its MFMAs
         }
         if (c + 1 < cend) store_chunk(buf ^ 1);
         __syncthreads();
+        if (c == cbeg) STAMP(4);
     }
+    STAMP(3);
 
-    // ---- epilogue ---------------------------------------------------------------------------------------------------------
-    // A lane holds column (lane & 31) and rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of each 32x32 block: the 16 rows sit at FIXED
-    // distances from the lane's first row, so every store / residual load is one buffer instruction with the lane's byte offset in
-    // the VGPR and the row distance in the (wave-uniform) scalar offset -- no per-element address arithmetic; rows past the end of
-    // the tensor get an out-of-range VGPR offset (one compare + select per element in the last row tile; the hardware's range
-    // check does not include the scalar offset) and are dropped by the hardware.  The activation is selected once, outside the
-    // element loops.  (The first version spent ~145 instructions per element here -- 64-bit row
-    // arithmetic, bounds tests and a branch tree per element -- and every wave of a launch runs its epilogue at the same time, so
-    // none of it overlapped with MFMA work: ~30 % of the kernel's cycles on the 64x64 layers.)
-    const int64_t out_elems = (int64_t)a.B * a.Hd * a.Wd * a.Ncols;
+    // ---- epilogue (epilogue_block above; split-K slices store raw partial sums instead) --------------------------------------
     if (a.ksplit > 1) {                                      // raw partial sums; the scale / shift / activation run after the reduction
         // plain form: slab z = [Ntot][Ncols]; class form: slab (z, class) = [cls_rows][Ncols] rows of the class lattice
-        const int64_t slab_id = CLS ? ((int64_t)blockIdx.z * 4 + (py * 2 + px)) * a.cls_rows : (int64_t)blockIdx.z * Ntot;
+        const int64_t slab_id = CLS ? ((int64_t)bz * 4 + (py * 2 + px)) * a.cls_rows : (int64_t)bz * Ntot;
         const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.slab + slab_id * a.Ncols), 0,
                                                                              (int)(Ntot * a.Ncols * 4), 0x00020000);
 #pragma unroll
@@ -351,72 +467,24 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         return;
     }
     if (!CLS) {
-        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(out_elems * 4), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, (int)(a.res ? out_elems * 4 : 0), 0x00020000);
-        const bool has_res = a.res != nullptr;
-        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)((TRANSPOSED && a.xin) ? a.xin : a.out), 0,
-                                                                             (int)((TRANSPOSED && a.xin) ? out_elems * 4 : 0), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc((void*)((TRANSPOSED && a.pre) ? a.pre : a.out), 0,
-                                                                             (int)((TRANSPOSED && a.pre) ? out_elems * 4 : 0), 0x00020000);
+        const EpiRsrc er = make_epi_rsrc<TRANSPOSED>(a);
 #pragma unroll
         for (int u = 0; u < TM; ++u)
 #pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                const int col = c0 + (wn * TN + t) * 32 + (lane & 31);
-                const bool col_ok = col < a.Ncols;
-                const float sc = (a.scale && col_ok) ? a.scale[col] : 1.f, sh = (a.shift && col_ok) ? a.shift[col] : 0.f;
-                const int64_t nb = n0 + (wm * TM + u) * 32 + 4 * khalf;
-                const unsigned voff0 = (col_ok && nb < Ntot) ? (unsigned)((nb * a.Ncols + col) * 4) : OOB;
-                const int left = (int)((Ntot - nb < 32) ? Ntot - nb : 32);      // rows of this block that exist: the hardware's range check
-                unsigned vo[16];                                                // ignores the scalar offset, so rows past the end are masked here
-#pragma unroll
-                for (int r = 0; r < 16; ++r) vo[r] = ((r & 3) + 8 * (r >> 2) < left) ? voff0 : OOB;
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[u][t][r], sc, sh);
-                if (TRANSPOSED && a.pre) {                      // a second gradient of the same tensor (residual branch)
-                    float pp[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        pp[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsp, vo[r], ((r & 3) + 8 * (r >> 2)) * a.Ncols * 4, 0));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] += pp[r];
-                }
-                if (TRANSPOSED && a.dact) {                     // x (act') of the tensor this gradient belongs to
-                    float xx[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        xx[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, vo[r], ((r & 3) + 8 * (r >> 2)) * a.Ncols * 4, 0));
-                    if (a.dact == ACT_RELU) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = xx[r] > 0.f ? v[r] : 0.f;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = xx[r] > 0.f ? v[r] : v[r] * (xx[r] + 1.f);
-                    }
-                }
-                if (has_res) {
-                    float rr[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        rr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsr, vo[r], ((r & 3) + 8 * (r >> 2)) * a.Ncols * 4, 0));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] += rr[r];
-                }
-                if (a.act == ACT_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-                } else if (a.act == ACT_ELU) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : expm1f(v[r]);
-                } else if (a.act == ACT_DISP) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = 10.f / (1.f + expf(-v[r])) + 0.01f;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rso, vo[r], ((r & 3) + 8 * (r >> 2)) * a.Ncols * 4, 0);
-            }
+            for (int t = 0; t < TN; ++t)
+                epilogue_block<TRANSPOSED>(a, er, acc[u][t], c0 + (wn * TN + t) * 32 + (lane & 31), n0 + (wm * TM + u) * 32 + 4 * khalf, Ntot);
+#ifdef E2E_CONV_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(5);
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 8192) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_stamps[blockIdx.x * 8 + 6] = hw;
+            g_stamps[blockIdx.x * 8 + 7] = xcc;
+        }
+#endif
         return;
     }
     // class form (3 small layers): GEMM row n = (b, yc, xc) of the class lattice -> output pixel (b, 2 yc + py, 2 xc + px); the image
@@ -444,6 +512,217 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
                 a.out[orow * a.Ncols + col] = apply_act(v, a.act);
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stream-K form of the same implicit GEMM (64x64 tiles, 2x2 waves, 16-byte channel-quad loader, forward and plain backward-data).
+//
+// Why: a conv layer of this network is ONE launch of 80 ... 2400 tiles x 18 ... 144 K-chunks on 256 CUs.  Tile-per-workgroup
+// grids lose to quantisation (600 tiles = 2.34 per SIMD cost what 3 cost) and, on the deep layers, need split-K slabs plus a
+// separate reduction launch (11 % of the GEMM family's time in round 2), and every workgroup pays its own prologue for one short
+// tile.  Here G persistent workgroups (2-3 per CU, all resident) share the flattened iteration space (tile, chunk) in equal
+// contiguous ranges: workgroup g owns iterations [I g / G, I (g + 1) / G).  A range that starts inside a tile begins with that
+// tile's REMAINDER: the workgroup stores the partial accumulator to its slab (write-through stores) and raises its flag.  A range
+// that ends inside a tile ends with that tile's HEAD (chunk 0 on): that workgroup is the tile's finisher -- it adds the slabs of
+// the workgroups g + 1, g + 2, ... that hold the rest of the tile, in that order (= increasing K: a fixed summation order,
+// bitwise reproducible), and runs the fused epilogue.  Everything else is whole tiles with the direct epilogue.
+//   * no deadlock: a finisher waits only for pieces that their owners process FIRST in their own ranges, before any wait of their
+//     own; all G workgroups are resident (G <= 4 per CU by LDS and registers), and even a late-scheduled owner is only waited for
+//     by workgroups that do not block its scheduling (everyone else runs to completion).  Spins are bounded; a time-out raises the
+//     error word flags[G] (read by the host through e2e_conv_streamk_error) instead of hanging the GPU;
+//   * hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): producer = sc1 (write-through) slab stores -> every wave
+//     s_waitcnt vmcnt(0) -> workgroup barrier -> ONE lane's relaxed agent-scope flag store; consumer = one lane polls the flag
+//     (relaxed, agent scope) -> agent-scope acquire -> s_waitcnt vmcnt(0) -> workgroup barrier -> sc1 loads of the slab;
+//   * flags are zero outside a launch: the finisher clears each flag it consumed (every flag has exactly one consumer), the
+//     owner of the workspace zeroes the flag region ONCE when it allocates it.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SkArgs {
+    float* slabs;          // [G][64 * 64]
+    unsigned* flags;       // [G] + error word
+    int G, tiles_n, C;     // workgroups, column tiles, K chunks per tile
+    long long I;           // tiles * C
+};
+#define SK_MAX_G 768        // most persistent workgroups of a stream-K launch (3 per CU)
+#define SK_FLAG_FLOATS 1024 // head of every convolution workspace: stream-K flags [SK_MAX_G] + error word, zeroed ONCE by the owner
+#define SK_ERR_INDEX SK_MAX_G
+#define SK_SC1 16           // aux bit of the buffer instructions: sc1 (system-coherent level 1 = write-through / L1 bypass on gfx950)
+
+template <bool TRANSPOSED, int CB>
+__global__ __launch_bounds__(256, 2) void k_conv_gemm_sk(ConvArgs a, SkArgs s) {
+    constexpr int BM = 64, BN = 64, NT = 256, KQ = CB / 4;
+    constexpr int A_PER = BM * KQ / NT, B_PER = CB * (BN / 4) / NT;          // CB = 32: 2 + 2 loads of 16 B per thread and chunk; 16: 1 + 1
+    static_assert(BM * KQ % NT == 0 && CB * (BN / 4) % NT == 0, "tile / thread-count mismatch");
+    __shared__ float As[2][CB][BM + 1];
+    __shared__ float Bs[2][CB][BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+    const int g = (int)xcd_contiguous(blockIdx.x, gridDim.x);          // consecutive iteration ranges (neighbouring tiles) share an XCD's L2
+    const int64_t Ntot = (int64_t)a.B * a.Hd * a.Wd;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)a.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0, (int)(a.src1 ? a.bytes1 : 0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.bytesw, 0x00020000);
+    const int sh = a.up >> 1, Hl = a.Hs >> sh, Wl = a.Ws >> sh, C2 = a.Cin - a.C1, cpt = a.Cin / CB, hw = a.Hd * a.Wd;
+    const int akq = tid % KQ, arow_l = wm * 32 + (lane & 31), khalf = lane >> 5;
+    int64_t it = s.I * g / s.G;
+    const int64_t it_end = s.I * (g + 1) / s.G;
+    while (it < it_end) {
+        const int tile = (int)(it / s.C), cb = (int)(it - (int64_t)tile * s.C);
+        const int ce = (int)((it_end - it < s.C - cb) ? cb + (it_end - it) : s.C);
+        const int tm = tile / s.tiles_n, tn = tile - tm * s.tiles_n;
+        const int64_t n0 = (int64_t)tm * BM;
+        const int c0 = tn * BN;
+        // ---- this tile's gather slots (same mapping as k_conv_gemm, VEC == 4) --------------------------------------------------
+        int arow[A_PER], ab[A_PER], ayd[A_PER], axd[A_PER];
+        bool arow_ok[A_PER];
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            arow[j] = (tid + j * NT) / KQ;
+            const int64_t an = n0 + arow[j];
+            arow_ok[j] = an < Ntot;
+            ab[j] = ayd[j] = axd[j] = 0;
+            if (arow_ok[j]) {
+                ab[j] = (int)(an / hw);
+                const int r = (int)(an - (int64_t)ab[j] * hw);
+                ayd[j] = r / a.Wd;
+                axd[j] = r - ayd[j] * a.Wd;
+            }
+        }
+        unsigned boff[B_PER];
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int idx = tid + j * NT, kr = idx / (BN / 4), cq = idx - kr * (BN / 4), col = c0 + cq * 4;
+            boff[j] = (col < a.ldw) ? (unsigned)(kr * a.ldw + col) * 4u : OOB;
+        }
+        int ld_kh, ld_kw, ld_cc;
+        unsigned off0[A_PER], off1[A_PER];
+        auto set_tap = [&]() {
+            const bool tap_ok = ld_kh < a.KH;
+#pragma unroll
+            for (int j = 0; j < A_PER; ++j) {
+                int ys = 0, xs = 0;
+                const bool ok = tap_ok && arow_ok[j] && tap_coord<TRANSPOSED>(a, ayd[j], axd[j], ld_kh, ld_kw, ys, xs);
+                const unsigned p0 = (unsigned)((ab[j] * Hl + (ys >> sh)) * Wl + (xs >> sh)) * (unsigned)a.C1 + (unsigned)(akq * 4);
+                const unsigned p1 = (unsigned)((ab[j] * a.Hs + ys) * a.Ws + xs) * (unsigned)C2 + (unsigned)(akq * 4);
+                off0[j] = ok ? p0 * 4u : OOB;
+                off1[j] = ok ? p1 * 4u : OOB;
+            }
+        };
+        {
+            const int t0 = cb / cpt;
+            ld_kh = t0 / a.KW;
+            ld_kw = t0 - ld_kh * a.KW;
+            ld_cc = cb - t0 * cpt;
+            set_tap();
+        }
+        f4v areg[A_PER], breg[B_PER];
+        auto load_chunk = [&]() {
+            const int cbase = ld_cc * CB;
+            const int krow = (ld_kh * a.KW + ld_kw) * a.Cin + cbase;
+            const bool use0 = cbase < a.C1;
+            const __amdgpu_buffer_rsrc_t rs = use0 ? rs0 : rs1;
+            const int soff = (use0 ? cbase : cbase - a.C1) * 4;
+#pragma unroll
+            for (int j = 0; j < A_PER; ++j)
+                areg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs, use0 ? off0[j] : off1[j], soff, 0));
+            if (++ld_cc == cpt) {
+                ld_cc = 0;
+                if (++ld_kw >= a.KW) { ld_kw = 0; ++ld_kh; }
+                set_tap();
+            }
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j)
+                breg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsw, boff[j], krow * a.ldw * 4, 0));
+        };
+        auto store_chunk = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < A_PER; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[buf][akq * 4 + e][arow[j]] = areg[j][e];
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j) {
+                const int idx = tid + j * NT, kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
+                *(f4v*)&Bs[buf][kr][cq * 4] = breg[j];
+            }
+        };
+        f16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        load_chunk();
+        store_chunk(0);
+        __syncthreads();
+        for (int c = cb; c < ce; ++c) {
+            const int buf = (c - cb) & 1;
+            if (c + 1 < ce) load_chunk();
+            float av[CB / 2], bv[CB / 2];                       // the chunk's fragments first, then the MFMAs (see k_conv_gemm)
+#pragma unroll
+            for (int kk = 0; kk < CB / 2; ++kk) {
+                av[kk] = As[buf][kk * 2 + khalf][arow_l];
+                bv[kk] = Bs[buf][kk * 2 + khalf][wn * 32 + (lane & 31)];
+            }
+#pragma unroll
+            for (int kk = 0; kk < CB / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, CB / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, CB / 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, CB / 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, CB / 2, 0);
+            if (c + 1 < ce) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+        // ---- what to do with the accumulator ------------------------------------------------------------------------------------
+        const unsigned sl_off = (unsigned)((wave * 4 * 64 + lane) * 16);         // this lane's first 16-byte quad inside a slab
+        if (cb != 0) {
+            // the tile's remainder: partial sums to this workgroup's slab, then the flag
+            const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(s.slabs + (int64_t)g * (BM * BN)), 0, BM * BN * 4, 0x00020000);
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v[r] = acc[r];
+                asm volatile("" : "+v"(v[r]));              // (see k_conv_gemm's slab store)
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4v t = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, t), rsl, sl_off + q * 64 * 16, 0, SK_SC1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(&s.flags[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (ce != s.C) {
+                // the tile's head: this workgroup finishes the tile with the pieces of g + 1, g + 2, ... (increasing K)
+                const int64_t tile_end = (int64_t)(tile + 1) * s.C;
+                int h_last = g;
+                for (int h = g + 1; h < s.G && s.I * h / s.G < tile_end; ++h) h_last = h;
+                if (tid == 0) {
+                    for (int h = g + 1; h <= h_last; ++h) {
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(&s.flags[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > (1u << 24)) { __hip_atomic_store(&s.flags[SK_ERR_INDEX], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                for (int h = g + 1; h <= h_last; ++h) {
+                    const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(s.slabs + (int64_t)h * (BM * BN)), 0, BM * BN * 4, 0x00020000);
+                    f4v t[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t[q] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsl, sl_off + q * 64 * 16, 0, SK_SC1));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[4 * q + e] += t[q][e];
+                }
+                if (tid == 0)
+                    for (int h = g + 1; h <= h_last; ++h) __hip_atomic_store(&s.flags[h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const EpiRsrc er = make_epi_rsrc<TRANSPOSED>(a);
+            epilogue_block<TRANSPOSED>(a, er, acc, c0 + wn * 32 + (lane & 31), n0 + wm * 32 + 4 * khalf, Ntot);
+        }
+        it += ce - cb;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -693,6 +972,18 @@ struct WgradArgs {
     int vec;
 };
 
+// XCD-contiguous order for the backward-weight grids: the column tiles (x) and row tiles (y) of ONE pixel slice (z) read the same dZ rows
+// and the same input rows -- they run on one XCD, back to back
+#define WGRAD_BLOCK_IDS                                                                                                                   \
+    unsigned bx, by, bz;                                                                                                                  \
+    {                                                                                                                                     \
+        const unsigned lin = xcd_contiguous(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z); \
+        bx = lin % gridDim.x;                                                                                                             \
+        const unsigned t_ = lin / gridDim.x;                                                                                              \
+        by = t_ % gridDim.y;                                                                                                              \
+        bz = t_ / gridDim.y;                                                                                                              \
+    }
+
 template <int WM, int WN, int VEC>
 __global__ __launch_bounds__(256) void k_wgrad_gemm(WgradArgs a) {
     constexpr int BM = 32 * WM, BN = 32 * WN, NT = 256;     // WM x WN = 4 waves, one 32x32 accumulator each
@@ -702,9 +993,10 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm(WgradArgs a) {
     __shared__ float Bs[2][CBK][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
-    const int m0 = blockIdx.y * BM, nn0 = blockIdx.x * BN;
+    WGRAD_BLOCK_IDS
+    const int m0 = by * BM, nn0 = bx * BN;
     const int64_t P = (int64_t)a.B * a.Ho * a.Wo;
-    const int64_t p0 = (int64_t)blockIdx.z * a.pix_per_slice;
+    const int64_t p0 = (int64_t)bz * a.pix_per_slice;
     const int64_t p1 = (p0 + a.pix_per_slice < P) ? p0 + a.pix_per_slice : P;
     const int nchunks = (p1 > p0) ? (int)((p1 - p0 + CBK - 1) / CBK) : 0;
     const int Hl = a.Hs / a.up, Wl = a.Ws / a.up, C2 = a.Cin - a.C1;
@@ -819,16 +1111,20 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm(WgradArgs a) {
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) load_chunk();
+        float av[CBK / 2], bv[CBK / 2];                           // the chunk's fragments first, then the MFMAs (see k_conv_gemm)
 #pragma unroll
         for (int kk = 0; kk < CBK / 2; ++kk) {
-            const float av = As[buf][kk * 2 + khalf][wm * 32 + (lane & 31)];
-            const float bv = Bs[buf][kk * 2 + khalf][wn * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            av[kk] = As[buf][kk * 2 + khalf][wm * 32 + (lane & 31)];
+            bv[kk] = Bs[buf][kk * 2 + khalf][wn * 32 + (lane & 31)];
         }
+#pragma unroll
+        for (int kk = 0; kk < CBK / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, CBK / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, CBK / 2, 0);
         if (c + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
     }
-    float* slab = a.slabs + (int64_t)blockIdx.z * a.Mpad * a.Npad;
+    float* slab = a.slabs + (int64_t)bz * a.Mpad * a.Npad;
     const int n = nn0 + wn * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -850,9 +1146,10 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
     __shared__ float Bs[2][CB][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
-    const int m0 = blockIdx.y * BM, nn0 = blockIdx.x * BN;
+    WGRAD_BLOCK_IDS
+    const int m0 = by * BM, nn0 = bx * BN;
     const int64_t P = (int64_t)a.B * a.Ho * a.Wo;
-    const int64_t p0 = (int64_t)blockIdx.z * a.pix_per_slice;
+    const int64_t p0 = (int64_t)bz * a.pix_per_slice;
     const int64_t p1 = (p0 + a.pix_per_slice < P) ? p0 + a.pix_per_slice : P;
     const int npix = (p1 > p0) ? (int)(p1 - p0) : 0;
     const int nchunks = (npix + CB - 1) / CB;
@@ -967,16 +1264,20 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) load_chunk();
+        float av[CB / 2], bv[CB / 2];                           // the chunk's fragments first, then the MFMAs (see k_conv_gemm)
 #pragma unroll
         for (int kk = 0; kk < CB / 2; ++kk) {
-            const float av = As[buf][kk * 2 + khalf][wm * 32 + (lane & 31)];
-            const float bv = Bs[buf][kk * 2 + khalf][wn * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            av[kk] = As[buf][kk * 2 + khalf][wm * 32 + (lane & 31)];
+            bv[kk] = Bs[buf][kk * 2 + khalf][wn * 32 + (lane & 31)];
         }
+#pragma unroll
+        for (int kk = 0; kk < CB / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, CB / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, CB / 2, 0);
         if (c + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
     }
-    float* slab = a.slabs + (int64_t)blockIdx.z * a.Mpad * a.Npad;
+    float* slab = a.slabs + (int64_t)bz * a.Mpad * a.Npad;
     const int n = nn0 + wn * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1001,9 +1302,11 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm16(WgradArgs a) {
     float (*As)[CB][BM] = reinterpret_cast<float (*)[CB][BM]>(smem);
     float (*Bs)[CB][BNS] = reinterpret_cast<float (*)[CB][BNS]>(smem + 2 * CB * BM);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nn0 = blockIdx.x * BN;
+    WGRAD_BLOCK_IDS
+    (void)by;
+    const int nn0 = bx * BN;
     const int64_t P = (int64_t)a.B * a.Ho * a.Wo;
-    const int64_t p0 = (int64_t)blockIdx.z * a.pix_per_slice;
+    const int64_t p0 = (int64_t)bz * a.pix_per_slice;
     const int64_t p1 = (p0 + a.pix_per_slice < P) ? p0 + a.pix_per_slice : P;
     const int npix = (p1 > p0) ? (int)(p1 - p0) : 0;
     const int nchunks = (npix + CB - 1) / CB;
@@ -1120,7 +1423,7 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm16(WgradArgs a) {
     }
     __syncthreads();
     if (wave > 0) return;
-    float* slab = a.slabs + (int64_t)blockIdx.z * a.Mpad * a.Npad;
+    float* slab = a.slabs + (int64_t)bz * a.Mpad * a.Npad;
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
@@ -1702,10 +2005,11 @@ static inline int egrid(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g
         else hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 4, TR, 16>), GRID, dim3(64 * WM * WN), 0, st, a);              \
     } while (0)
 
-// A GEMM decomposition: rows x columns of the workgroup tile and the number of K slices (split-K).
+// A GEMM decomposition: rows x columns of the workgroup tile and the number of K slices (split-K); S < 0: stream-K on -S persistent
+// workgroups (k_conv_gemm_sk, 64x64 tiles).  bm == 0: not forced.  Tuning choices travel PER CALL (the *_tuned entry points); the
+// library keeps no mutable state.
 struct GemmCfg { int bm, bn, S; };
-static int g_wgrad_target = 1024;          // workgroups a backward-weight launch aims at (tuning hook: e2e_conv_wgrad_target)
-static GemmCfg g_force = {0, 0, 0};          // tuning hook (tools/gemm_tune.py): e2e_conv_gemm_force(); 0 = automatic choice
+#define WGRAD_TARGET 1024                   // workgroups a backward-weight launch aims at by default
 
 // waves of a tile shape (one 32x32xTMxTN accumulator block per wave) -- 0: unsupported shape
 static int tile_waves(int bm, int bn) {
@@ -1724,8 +2028,8 @@ static int tile_waves(int bm, int bn) {
 //     S = 12 -- as long as a slice keeps at least 128 of K.  Finer tiles WITHOUT split-K (32x64, 32x32: 1200-2400 workgroups)
 //     do not pay: the kernels are not bound by tile quantisation but by the phases every wave of a launch goes through at
 //     the same time (operand set-up, epilogue), which more but smaller workgroups do not shorten.
-static GemmCfg choose_cfg(int64_t rows, int cols, int K, int cb, bool allow_split) {
-    if (g_force.bm) { GemmCfg f = g_force; if (!allow_split) f.S = 1; if (f.bm == 128 && f.bn == 128 && cb != 16) f.bn = 64; return f; }
+static GemmCfg choose_cfg(int64_t rows, int cols, int K, int cb, bool allow_split, GemmCfg force = GemmCfg{0, 0, 0}) {
+    if (force.bm) { GemmCfg f = force; if (!allow_split && f.S > 1) f.S = 1; if (f.bm == 128 && f.bn == 128 && cb != 16) f.bn = 64; return f; }
     GemmCfg c = {64, 64, 1};
     if (cols <= 32) {
         c.bm = 128; c.bn = 32;
@@ -1757,16 +2061,29 @@ static void launch_tile(ConvArgs& a, int cb, GemmCfg c, dim3 g, hipStream_t st) 
     else GEMM_LAUNCH(1, 1, 1, 1, g);
 }
 
-static int64_t splitk_max_floats(int64_t rows, int cols, int K, int vec) {
-    if (vec != 4) return 0;
-    return (int64_t)16 * rows * cols;            // the chooser never takes more than 16 slices
+// stream-K launch: G persistent workgroups over tiles x chunks (see k_conv_gemm_sk).  workspace = [flags | slabs]
+template <bool TR>
+static void launch_streamk(ConvArgs& a, int cb, int G, float* workspace, hipStream_t st) {
+    const int64_t Ntot = (int64_t)a.B * a.Hd * a.Wd;
+    SkArgs s;
+    s.flags = (unsigned*)workspace;
+    s.slabs = workspace + SK_FLAG_FLOATS;
+    s.tiles_n = (a.Ncols + 63) / 64;
+    s.C = a.KH * a.KW * a.Cin / cb;
+    s.I = ((Ntot + 63) / 64) * s.tiles_n * (long long)s.C;
+    if (G > SK_MAX_G) G = SK_MAX_G;
+    if ((long long)G > s.I) G = (int)s.I;                    // every workgroup owns at least one iteration
+    s.G = G;
+    if (cb == 32) hipLaunchKernelGGL((k_conv_gemm_sk<TR, 32>), dim3(G), dim3(256), 0, st, a, s);
+    else hipLaunchKernelGGL((k_conv_gemm_sk<TR, 16>), dim3(G), dim3(256), 0, st, a, s);
 }
 
 template <bool TR>
-static void launch_gemm(ConvArgs a, int vec, float* workspace, hipStream_t st) {
+static void launch_gemm(ConvArgs a, int vec, float* workspace_all, GemmCfg force, hipStream_t st) {
     const int64_t Ntot = (int64_t)a.B * a.Hd * a.Wd;
     const int K = a.KH * a.KW * a.Cin;
     const int cb = (vec == 4 && a.Cin % 32 == 0 && (a.C1 == a.Cin || a.C1 % 32 == 0)) ? 32 : 16;
+    float* workspace = workspace_all ? workspace_all + SK_FLAG_FLOATS : nullptr;     // split-K slabs live behind the stream-K flag region
     a.ksplit = 1; a.cps = 0; a.slab = workspace;
     a.bytes0 = (int64_t)a.B * (a.Hs / a.up) * (a.Ws / a.up) * a.C1 * 4;
     a.bytes1 = (int64_t)a.B * a.Hs * a.Ws * (a.Cin - a.C1) * 4;
@@ -1780,7 +2097,7 @@ static void launch_gemm(ConvArgs a, int vec, float* workspace, hipStream_t st) {
         // 4 parity classes x the tiles of the largest class (ceil(Hd/2) x ceil(Wd/2) pixels per image); blockIdx.x & 3 = class.
         // The classes carry 1, 2, 2 and 4 of the 9 taps: price the decomposition on the average (K * 9/16 of a class of Nc rows x 4)
         const int64_t Nc = (int64_t)a.B * ((a.Hd + 1) / 2) * ((a.Wd + 1) / 2);
-        GemmCfg c = choose_cfg(Nc * 4, a.Ncols, (K * 9 / 16 + cb - 1) / cb * cb, cb, false);
+        GemmCfg c = choose_cfg(Nc * 4, a.Ncols, (K * 9 / 16 + cb - 1) / cb * cb, cb, false, force.S < 0 ? GemmCfg{0, 0, 0} : force);
         if (c.bm == 128 && c.bn == 128) c.bn = 64;
         // The classes of a 3x3 kernel carry 4, 2, 2 and 1 taps: with so few workgroups the launch lasts as long as a 4-tap one
         // (l4.0.conv1: 57 us against 26 us for the forward).  Slice every class by TAP: equal work per workgroup, partial sums in
@@ -1800,7 +2117,11 @@ static void launch_gemm(ConvArgs a, int vec, float* workspace, hipStream_t st) {
         launch_tile<TR>(a, cb, c, g, st);
         return;
     }
-    const GemmCfg c = choose_cfg(Ntot, a.Ncols, K, cb, workspace != nullptr);
+    const GemmCfg c = choose_cfg(Ntot, a.Ncols, K, cb, workspace != nullptr, force);
+    if (c.S < 0 && workspace && vec == 4 && K % cb == 0 && a.Cin % cb == 0) {      // stream-K (64x64 tiles)
+        launch_streamk<TR>(a, cb, -c.S, workspace_all, st);
+        return;
+    }
     if (c.S > 1) {
         const int nchunks = (K + cb - 1) / cb;
         a.cps = (nchunks + c.S - 1) / c.S;
@@ -1843,33 +2164,39 @@ int e2e_conv_weight_layouts_batched(const long long* desc, int nlayers, void* st
     return E2E_OK;
 }
 
-/* floats of split-K workspace a GEMM of `rows` x `cols` with reduction length K may use (0: never splits) */
+/* floats of workspace a GEMM of `rows` x `cols` with reduction length K may use: the stream-K flag region (SK_FLAG_FLOATS, which the
+ * owner zeroes ONCE after allocating) followed by split-K slabs or stream-K slabs, whichever is larger (0: the layer takes neither) */
 int64_t e2e_conv2d_splitk_workspace_floats(int64_t rows, int cols, int K);
 /* workspace of a backward-data call: the split-K slabs of the stride-1 form, or the (tap, class) slabs of the stride-2 class form */
 int64_t e2e_conv2d_bwd_data_workspace_floats(int B, int Hd, int Wd, int cols, int K, int stride) {
     const int64_t plain = e2e_conv2d_splitk_workspace_floats((int64_t)B * Hd * Wd, cols, K);
     if (stride != 2) return plain;
-    const int64_t cls = (int64_t)16 * B * ((Hd + 1) / 2) * ((Wd + 1) / 2) * cols;      // 4 tap slices x 4 classes x the largest class
+    const int64_t cls = SK_FLAG_FLOATS + (int64_t)16 * B * ((Hd + 1) / 2) * ((Wd + 1) / 2) * cols;      // 4 tap slices x 4 classes x the largest class
     return cls > plain ? cls : plain;
 }
 
 int64_t e2e_conv2d_splitk_workspace_floats(int64_t rows, int cols, int K) {
     if (K % 16 != 0) return 0;
     int smax = 1;                                            // the largest slice count any chunk depth would choose
+    bool sk = false;
     for (int cb = 16; cb <= 32; cb += 16) {
         const GemmCfg c = choose_cfg(rows, cols, K, cb, true);
         if (c.S > smax) smax = c.S;
+        if (c.S < 0) sk = true;
     }
-    if (g_force.bm && g_force.S > smax) smax = g_force.S;
-    return smax > 1 ? (int64_t)smax * rows * cols : 0;
+    int64_t n = smax > 1 ? (int64_t)smax * rows * cols : 0;
+    if (sk && n < (int64_t)SK_MAX_G * 64 * 64) n = (int64_t)SK_MAX_G * 64 * 64;
+    return n ? n + SK_FLAG_FLOATS : 0;
 }
 
-/* tuning hook: number of workgroups a backward-weight launch spreads its pixel slices over (default 1024) */
-int e2e_conv_wgrad_target(int workgroups) {
-    E2E_REQUIRE(workgroups >= 64 && workgroups <= 8192, E2E_ERR_ARG, "e2e_conv_wgrad_target: 64..8192");
-    g_wgrad_target = workgroups;
-    return E2E_OK;
+/* workspace that covers ANY tile / split-K (<= 16 slices) / stream-K choice of a *_tuned call on a GEMM of rows x cols */
+int64_t e2e_conv_tuned_workspace_floats(int64_t rows, int cols) {
+    int64_t n = (int64_t)16 * rows * cols;
+    if (n < (int64_t)SK_MAX_G * 64 * 64) n = (int64_t)SK_MAX_G * 64 * 64;
+    return n + SK_FLAG_FLOATS;
 }
+int e2e_conv_workspace_flag_floats(void) { return SK_FLAG_FLOATS; }
+int e2e_conv_streamk_error_index(void) { return SK_ERR_INDEX; }
 
 /* the decomposition the built-in cost model picks for a GEMM of rows x cols x K at chunk depth cb (host-only query) */
 int e2e_conv_gemm_choice(int64_t rows, int cols, int K, int chunk_depth, int allow_split, int* out3) {
@@ -1879,17 +2206,9 @@ int e2e_conv_gemm_choice(int64_t rows, int cols, int K, int chunk_depth, int all
     return E2E_OK;
 }
 
-/* tuning hook: force the tile shape / slice count of every following GEMM launch (bm = 0: automatic).  Not thread safe;
- * used by tools/gemm_tune.py only. */
-int e2e_conv_gemm_force(int bm, int bn, int ksplit) {
-    E2E_REQUIRE(bm == 0 || (tile_waves(bm, bn) != 0 && ksplit >= 1 && ksplit <= 16), E2E_ERR_ARG, "e2e_conv_gemm_force: unsupported tile");
-    g_force.bm = bm; g_force.bn = bn; g_force.S = ksplit;
-    return E2E_OK;
-}
-
-int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const float* w_fwd, int ld_fwd, const float* scale,
-                   const float* shift, const float* residual, float* out, int B, int Hs, int Ws, int Cin, int Cout, int KH,
-                   int KW, int stride, int pad, int pad_mode, int act, float in_sub, float in_mul, float* workspace, void* stream) {
+static int conv_fwd_impl(const float* src0, const float* src1, int C1, int up, const float* w_fwd, int ld_fwd, const float* scale,
+                         const float* shift, const float* residual, float* out, int B, int Hs, int Ws, int Cin, int Cout, int KH,
+                         int KW, int stride, int pad, int pad_mode, int act, float in_sub, float in_mul, float* workspace, GemmCfg force, void* stream) {
     E2E_REQUIRE(src0 && w_fwd && out && B > 0 && Hs > 0 && Ws > 0 && Cin > 0 && Cout > 0, E2E_ERR_ARG, "e2e_conv2d_fwd: bad argument");
     E2E_REQUIRE(up == 1 || up == 2, E2E_ERR_ARG, "e2e_conv2d_fwd: upsample factor must be 1 or 2");
     E2E_REQUIRE(C1 > 0 && C1 <= Cin && (C1 == Cin || src1), E2E_ERR_ARG, "e2e_conv2d_fwd: bad channel split");
@@ -1907,14 +2226,14 @@ int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const f
     a.Ncols = Cout; a.ldw = ld_fwd; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_mode = pad_mode; a.off = 0; a.act = act;
     a.in_sub = in_sub; a.in_mul = in_mul;
     // the RGB stem: patch kernel
-    if (KH == 7 && KW == 7 && stride == 2 && pad == 3 && pad_mode == 0 && Cin == 3 && Cout == 64 && C1 == Cin && up == 1 && !residual && ld_fwd >= 64) {
+    if (!force.bm && KH == 7 && KW == 7 && stride == 2 && pad == 3 && pad_mode == 0 && Cin == 3 && Cout == 64 && C1 == Cin && up == 1 && !residual && ld_fwd >= 64) {
         StemArgs t{src0, w_fwd, scale, shift, out, B, Hs, Ws, a.Hd, a.Wd, ld_fwd, act, in_sub, in_mul};
         hipLaunchKernelGGL(k_conv7x7_stem, dim3((a.Wd + 31) / 32, (a.Hd + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, t);
         E2E_LAUNCH_CHECK("e2e_conv2d_fwd");
         return E2E_OK;
     }
     // the two 16-output-channel layers at the decoder's last level: patch-in-LDS kernel (k_conv3x3_thin)
-    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && pad_mode == 1 && Cout == 16 && C1 == Cin && !scale && !residual && ld_fwd >= 16 &&
+    if (!force.bm && KH == 3 && KW == 3 && stride == 1 && pad == 1 && pad_mode == 1 && Cout == 16 && C1 == Cin && !scale && !residual && ld_fwd >= 16 &&
         ((Cin == 16 && up == 2) || (Cin == 32 && up == 1))) {
         ThinArgs t{src0, w_fwd, shift, out, B, Hs / up, Ws / up, Hs, Ws, ld_fwd, act, 1, 0};
         if (Cin == 16) hipLaunchKernelGGL((k_conv3x3_thin<16, 2, true, 8>), dim3((Ws + 63) / 64, (Hs + 7) / 8, B), dim3(256), 0, (hipStream_t)stream, t);
@@ -1922,14 +2241,38 @@ int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const f
         E2E_LAUNCH_CHECK("e2e_conv2d_fwd");
         return E2E_OK;
     }
-    launch_gemm<false>(a, vec, workspace, (hipStream_t)stream);
+    launch_gemm<false>(a, vec, workspace, force, (hipStream_t)stream);
     E2E_LAUNCH_CHECK("e2e_conv2d_fwd");
     return E2E_OK;
 }
 
+int e2e_conv2d_fwd(const float* src0, const float* src1, int C1, int up, const float* w_fwd, int ld_fwd, const float* scale,
+                   const float* shift, const float* residual, float* out, int B, int Hs, int Ws, int Cin, int Cout, int KH,
+                   int KW, int stride, int pad, int pad_mode, int act, float in_sub, float in_mul, float* workspace, void* stream) {
+    return conv_fwd_impl(src0, src1, C1, up, w_fwd, ld_fwd, scale, shift, residual, out, B, Hs, Ws, Cin, Cout, KH, KW, stride, pad, pad_mode, act, in_sub, in_mul,
+                         workspace, GemmCfg{0, 0, 0}, stream);
+}
+
+// a tuned call's decomposition: tile_m x tile_n workgroup tiles; ksplit >= 1: that many K slices, ksplit < 0: stream-K on -ksplit
+// persistent workgroups (64 x 64 tiles); tile_m == 0: the library's own choice
+static bool tuning_ok(int tile_m, int tile_n, int ksplit) {
+    if (tile_m == 0) return true;
+    if (ksplit < 0) return tile_m == 64 && tile_n == 64 && -ksplit <= SK_MAX_G;
+    return tile_waves(tile_m, tile_n) != 0 && ksplit >= 1 && ksplit <= 16;
+}
+
+int e2e_conv2d_fwd_tuned(const float* src0, const float* src1, int C1, int up, const float* w_fwd, int ld_fwd, const float* scale,
+                         const float* shift, const float* residual, float* out, int B, int Hs, int Ws, int Cin, int Cout, int KH,
+                         int KW, int stride, int pad, int pad_mode, int act, float in_sub, float in_mul, float* workspace, int tile_m, int tile_n,
+                         int ksplit, void* stream) {
+    E2E_REQUIRE(tuning_ok(tile_m, tile_n, ksplit), E2E_ERR_ARG, "e2e_conv2d_fwd_tuned: unsupported decomposition %d x %d / %d", tile_m, tile_n, ksplit);
+    return conv_fwd_impl(src0, src1, C1, up, w_fwd, ld_fwd, scale, shift, residual, out, B, Hs, Ws, Cin, Cout, KH, KW, stride, pad, pad_mode, act, in_sub, in_mul,
+                         workspace, GemmCfg{tile_m, tile_n, ksplit}, stream);
+}
+
 static int bwd_data_impl(const float* dz, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout, int Ho, int Wo,
                          int KH, int KW, int stride, int pad, int pad_mode, int accumulate, const float* x_in, int in_act, const float* pre_add,
-                         float* workspace, void* stream) {
+                         float* workspace, void* stream, GemmCfg force = GemmCfg{0, 0, 0}) {
     E2E_REQUIRE(pre_add == nullptr || pad_mode == 0, E2E_ERR_ARG, "e2e_conv2d_bwd_data: the pre-activation addend takes a zero-padded layer");
     E2E_REQUIRE(in_act == 0 || (x_in && (in_act == ACT_RELU || in_act == ACT_ELU) && pad_mode == 0), E2E_ERR_ARG,
                 "e2e_conv2d_bwd_data: the fused input-activation derivative takes ReLU / ELU, the activation's output and a zero-padded layer");
@@ -1938,7 +2281,7 @@ static int bwd_data_impl(const float* dz, const float* w_bwd, int ld_bwd, float*
     E2E_REQUIRE((int64_t)B * Ho * Wo * Cout * 4 < (1ll << 31) && (int64_t)KH * KW * Cout * ld_bwd * 4 < (1ll << 31), E2E_ERR_ARG,
                 "e2e_conv2d_bwd_data: operands must stay below 2 GB (32-bit buffer offsets)");
     // 16 -> 16 channels on the padded grid of a reflection-padded layer (upconv(0,1)): dXp[q] = sum_t dZ[q - t] Wb[t], patch kernel
-    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && pad_mode == 1 && Cin == 16 && Cout == 16 && !accumulate && !in_act && !pre_add && ld_bwd >= 16) {
+    if (!force.bm && KH == 3 && KW == 3 && stride == 1 && pad == 1 && pad_mode == 1 && Cin == 16 && Cout == 16 && !accumulate && !in_act && !pre_add && ld_bwd >= 16) {
         ThinArgs t{dz, w_bwd, nullptr, dxp, B, Ho, Wo, Hs + 2, Ws + 2, ld_bwd, ACT_NONE, 2, 1};
         hipLaunchKernelGGL((k_conv3x3_thin<16, 1, false, 8>), dim3((Ws + 2 + 63) / 64, (Hs + 2 + 7) / 8, B), dim3(256), 0, (hipStream_t)stream, t);
         E2E_LAUNCH_CHECK("e2e_conv2d_bwd_data");
@@ -1958,7 +2301,7 @@ static int bwd_data_impl(const float* dz, const float* w_bwd, int ld_bwd, float*
     // accumulate: dxp += result -- the epilogue's residual input reads the element it is about to overwrite (same thread)
     if (accumulate) a.res = dxp;
     a.xin = in_act ? x_in : nullptr; a.dact = in_act; a.pre = pre_add;
-    launch_gemm<true>(a, 4, workspace, (hipStream_t)stream);
+    launch_gemm<true>(a, 4, workspace, force, (hipStream_t)stream);
     E2E_LAUNCH_CHECK("e2e_conv2d_bwd_data");
     return E2E_OK;
 }
@@ -1979,6 +2322,14 @@ int e2e_conv2d_bwd_data_fused(const float* da, const float* w_bwd, int ld_bwd, f
                               int in_act, const float* pre_add, float* workspace, void* stream) {
     return bwd_data_impl(da, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate, x_in, in_act, pre_add, workspace,
                          stream);
+}
+
+int e2e_conv2d_bwd_data_fused_tuned(const float* da, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout,
+                                    int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, int accumulate, const float* x_in,
+                                    int in_act, const float* pre_add, float* workspace, int tile_m, int tile_n, int ksplit, void* stream) {
+    E2E_REQUIRE(tuning_ok(tile_m, tile_n, ksplit), E2E_ERR_ARG, "e2e_conv2d_bwd_data_fused_tuned: unsupported decomposition %d x %d / %d", tile_m, tile_n, ksplit);
+    return bwd_data_impl(da, w_bwd, ld_bwd, dxp, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate, x_in, in_act, pre_add, workspace,
+                         stream, GemmCfg{tile_m, tile_n, ksplit});
 }
 
 // launch the adjoint of pad + upsample + concat: 16-byte channel quads when the channel split allows, 32-bit indices
@@ -2060,7 +2411,7 @@ int e2e_head_bwd_act(const float* dz, const float* x, const float* w, float* dx,
 
 // backward-weight decomposition shared by the workspace query and the launch: tile shape, padded GEMM size, pixel slices
 struct WgradPlan { int tm, tn, Mpad, Npad; int64_t S; };
-static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int has_bias, bool use16) {
+static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int has_bias, bool use16, int wg_target = WGRAD_TARGET) {
     WgradPlan p;
     const int Ng = KH * KW * Cin + (has_bias ? 1 : 0);
     p.tm = Cout <= 32 ? 32 : 64; p.tn = Cout <= 32 ? 128 : 64;        // 32x128 tiles for the thin layers
@@ -2068,7 +2419,7 @@ static WgradPlan wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, in
     p.Mpad = (Cout + p.tm - 1) / p.tm * p.tm; p.Npad = (Ng + p.tn - 1) / p.tn * p.tn;
     const int64_t P = (int64_t)B * Ho * Wo;
     const int64_t tiles = (int64_t)(p.Mpad / p.tm) * (p.Npad / p.tn);
-    const int target = use16 ? g_wgrad_target * 3 / 4 : g_wgrad_target;     // measured: 768 slices suit the 16-channel kernel (94 vs 110 us)
+    const int target = use16 ? wg_target * 3 / 4 : wg_target;     // measured: 768 slices suit the 16-channel kernel (94 vs 110 us)
     int64_t S = (target + tiles - 1) / tiles;                // pixel slices: ~target workgroups in total
     const int64_t maxS = (P + 255) / 256;                   // at least 256 pixels per slice
     if (S > maxS) S = maxS;
@@ -2117,7 +2468,9 @@ int64_t e2e_conv2d_wgrad_workspace_floats(int B, int Ho, int Wo, int Cin, int Co
 
 static int bwd_weight_impl(const float* dz, const float* src0, const float* src1, int C1, int up, float* dw, float* dbias, float* workspace, int B,
                            int Hs, int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, int accumulate,
-                           float in_sub, float in_mul, const float* out_scale, void* stream) {
+                           float in_sub, float in_mul, const float* out_scale, void* stream, int wg_target = 0) {
+    const bool tuned = wg_target != 0;
+    if (!tuned) wg_target = WGRAD_TARGET;
     E2E_REQUIRE(dz && src0 && dw && workspace && B > 0 && Cin > 0 && Cout > 0, E2E_ERR_ARG, "e2e_conv2d_bwd_weight: bad argument");
     const int vec = (Cin % 4 == 0 && C1 % 4 == 0) ? 4 : 1;
     E2E_REQUIRE(vec == 4 || (C1 == Cin && up == 1 && pad_mode == 0), E2E_ERR_ARG, "e2e_conv2d_bwd_weight: scalar path takes one full-resolution zero-padded source");
@@ -2142,7 +2495,7 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
         return E2E_OK;
     }
     // the thin 3x3 layers of the decoder's last two levels (reflection pad, 16 / 32 output channels): patch kernel + the common slab reduction
-    if (lean && thin_wgrad_ok(Cin, Cout, KH, KW) && stride == 1 && pad == 1 && pad_mode == 1 && C1 % 16 == 0 && Ho == Hs && Wo == Ws &&
+    if (!tuned && lean && thin_wgrad_ok(Cin, Cout, KH, KW) && stride == 1 && pad == 1 && pad_mode == 1 && C1 % 16 == 0 && Ho == Hs && Wo == Ws &&
         (C1 == Cin || src1) && Hs % up == 0 && Ws % up == 0) {
         const ThinWgradPlan t = thin_wgrad_plan(B, Ho, Wo, Cin, a.has_bias);
         ThinWgradArgs ta{dz, src0, src1, workspace, B, Ho, Wo, Cin, C1, up, t.npad, a.has_bias, t.tiles_x, t.nxg};
@@ -2156,7 +2509,7 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
         return E2E_OK;
     }
     const bool use16 = lean && Cout == 16;
-    const WgradPlan wp = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW, a.has_bias, use16);
+    const WgradPlan wp = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW, a.has_bias, use16, wg_target);
     const int tm = wp.tm, tn = wp.tn;
     a.Mpad = wp.Mpad; a.Npad = wp.Npad;
     a.in_sub = in_sub; a.in_mul = in_mul; a.vec = vec;
@@ -2201,5 +2554,31 @@ int e2e_conv2d_bwd_weight_scaled(const float* da, const float* out_scale, const 
     return bwd_weight_impl(da, src0, src1, C1, up, dw, dbias, workspace, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate,
                            in_sub, in_mul, out_scale, stream);
 }
+
+/* the same through the implicit-GEMM kernels with an explicit number of workgroups to spread the pixel slices over (64 .. 8192; tools/gemm_tune.py).
+ * workspace: e2e_conv2d_wgrad_tuned_workspace_floats(...) floats */
+int e2e_conv2d_bwd_weight_scaled_tuned(const float* da, const float* out_scale, const float* src0, const float* src1, int C1, int up, float* dw,
+                                       float* dbias, float* workspace, int B, int Hs, int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW,
+                                       int stride, int pad, int pad_mode, int accumulate, float in_sub, float in_mul, int target_workgroups, void* stream) {
+    E2E_REQUIRE(target_workgroups >= 64 && target_workgroups <= 8192, E2E_ERR_ARG, "e2e_conv2d_bwd_weight_scaled_tuned: 64 .. 8192 workgroups");
+    return bwd_weight_impl(da, src0, src1, C1, up, dw, dbias, workspace, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate,
+                           in_sub, in_mul, out_scale, stream, target_workgroups);
+}
+
+int64_t e2e_conv2d_wgrad_tuned_workspace_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int has_bias, int target_workgroups) {
+    int64_t n = 0;
+    for (int u = 0; u < 2; ++u) {
+        if (u == 1 && Cout != 16) break;
+        const WgradPlan p = wgrad_plan(B, Ho, Wo, Cin, Cout, KH, KW, has_bias, u == 1, target_workgroups);
+        if (p.S * (int64_t)p.Mpad * p.Npad > n) n = p.S * (int64_t)p.Mpad * p.Npad;
+    }
+    return n;
+}
+
+#ifdef E2E_CONV_STAMPS
+int e2e_debug_read_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * 8);
+}
+#endif
 
 }  // extern "C"

@@ -98,8 +98,13 @@ SIGNATURES = {
     "e2e_conv2d_fwd": [c_fp, c_fp, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp] + [c_int] * 11 + [c_f32, c_f32, c_fp, c_fp],
     "e2e_conv2d_splitk_workspace_floats": [c_i64, c_int, c_int],
     "e2e_conv2d_bwd_data_workspace_floats": [c_int, c_int, c_int, c_int, c_int, c_int],
-    "e2e_conv_gemm_force": [c_int, c_int, c_int],
-    "e2e_conv_wgrad_target": [c_int],
+    "e2e_conv2d_fwd_tuned": [c_fp, c_fp, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp] + [c_int] * 11 + [c_f32, c_f32, c_fp, c_int, c_int, c_int, c_fp],
+    "e2e_conv2d_bwd_data_fused_tuned": [c_fp, c_fp, c_int, c_fp] + [c_int] * 13 + [c_fp, c_int, c_fp, c_fp, c_int, c_int, c_int, c_fp],
+    "e2e_conv2d_bwd_weight_scaled_tuned": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp] + [c_int] * 13 + [c_f32, c_f32, c_int, c_fp],
+    "e2e_conv2d_wgrad_tuned_workspace_floats": [c_int] * 9,
+    "e2e_conv_tuned_workspace_floats": [c_i64, c_int],
+    "e2e_conv_workspace_flag_floats": [],
+    "e2e_conv_streamk_error_index": [],
     "e2e_conv_gemm_choice": [c_i64, c_int, c_int, c_int, c_int, c_fp],
     "e2e_conv2d_act_bwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp],
     "e2e_conv2d_bwd_data": [c_fp, c_fp, c_int, c_fp] + [c_int] * 12 + [c_fp, c_fp],
@@ -131,7 +136,7 @@ _RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats"
             "e2e_warp_photo_lossgrad_workspace_floats": c_i64, "e2e_pf_workspace_bytes": c_i64,
             "e2e_knn1_workspace_bytes": c_i64, "e2e_knn1_index_capacity_bytes": c_i64, "e2e_median_workspace_bytes": c_i64,
             "e2e_depth_scale_workspace_bytes": c_i64, "e2e_reduce_workspace_floats": c_i64,
-            "e2e_conv2d_wgrad_workspace_floats": c_i64, "e2e_conv2d_splitk_workspace_floats": c_i64, "e2e_conv2d_bwd_data_workspace_floats": c_i64,
+            "e2e_conv2d_wgrad_workspace_floats": c_i64, "e2e_conv2d_wgrad_tuned_workspace_floats": c_i64, "e2e_conv_tuned_workspace_floats": c_i64, "e2e_conv2d_splitk_workspace_floats": c_i64, "e2e_conv2d_bwd_data_workspace_floats": c_i64,
             "e2e_head_workspace_floats": c_i64, "e2e_icp_workspace_bytes": c_i64, "e2e_aux_workspace_floats": c_i64,
             "e2e_affine_bwd_workspace_floats": c_i64}
 

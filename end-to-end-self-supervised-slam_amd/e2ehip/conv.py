@@ -320,6 +320,39 @@ def _ld(n):
     return (n + 3) // 4 * 4
 
 
+TUNING = [None]       # (tile_m, tile_n, ksplit) forced on the GEMMs of this MODULE path by tools / tests (gemm_tuning); the library itself is stateless
+
+
+class gemm_tuning:
+    """with gemm_tuning(tile_m, tile_n, ksplit): every conv2d forward / backward-data inside runs that decomposition (ksplit >= 1: K
+    slices, < 0: stream-K on -ksplit persistent workgroups of 64 x 64 tiles) through the *_tuned entry points."""
+
+    def __init__(self, tile_m, tile_n, ksplit):
+        self.t = (int(tile_m), int(tile_n), int(ksplit))
+
+    def __enter__(self):
+        self.prev, TUNING[0] = TUNING[0], self.t
+        return self
+
+    def __exit__(self, *exc):
+        TUNING[0] = self.prev
+
+
+def _gemm_workspace(n, dev):
+    """A convolution GEMM workspace: its head (e2e_conv_workspace_flag_floats) holds the stream-K flags, zero outside a launch."""
+    if not n:
+        return None
+    ws = torch.empty(n, device=dev, dtype=torch.float32)
+    ws[: L.load().e2e_conv_workspace_flag_floats()].zero_()
+    return ws
+
+
+def check_streamk(ws):
+    """Raises if a stream-K launch that used this workspace timed out waiting for a partial tile (host sync)."""
+    if ws is not None and int(ws.view(torch.int32)[L.load().e2e_conv_streamk_error_index()]) != 0:
+        raise L.E2EError("stream-K convolution: a workgroup timed out waiting for a partial tile")
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src0, src1, weight, bias, scale, shift, residual, up, stride, pad, pad_mode, act, in_norm, wf, wb):
@@ -350,10 +383,18 @@ class _Conv2d(torch.autograd.Function):
             residual = _cl(L.dev(residual, "residual"))
         out = torch.empty(B, Cout, Ho, Wo, device=dev, dtype=torch.float32, memory_format=CL)
         isub, imul = in_norm if in_norm is not None else (0.0, 1.0)
-        nws = L.load().e2e_conv2d_splitk_workspace_floats(B * Ho * Wo, Cout, KH * KW * Cin)
-        ws = torch.empty(nws, device=dev, dtype=torch.float32) if nws else None
-        L.call("e2e_conv2d_fwd", L.ptr(src0), L.ptr(src1), C1, up, L.ptr(wf), ldf, L.ptr(scale), L.ptr(sh), L.ptr(residual), L.ptr(out),
-               B, Hs, Ws, Cin, Cout, KH, KW, stride, pad, pad_mode, act, float(isub), float(imul), L.ptr(ws), L.stream())
+        tune = TUNING[0]
+        if tune is not None:
+            ws = _gemm_workspace(L.load().e2e_conv_tuned_workspace_floats(B * Ho * Wo, Cout), dev)
+            L.call("e2e_conv2d_fwd_tuned", L.ptr(src0), L.ptr(src1), C1, up, L.ptr(wf), ldf, L.ptr(scale), L.ptr(sh), L.ptr(residual), L.ptr(out),
+                   B, Hs, Ws, Cin, Cout, KH, KW, stride, pad, pad_mode, act, float(isub), float(imul), L.ptr(ws), tune[0], tune[1], tune[2], L.stream())
+            if tune[2] < 0:
+                check_streamk(ws)
+        else:
+            ws = _gemm_workspace(L.load().e2e_conv2d_splitk_workspace_floats(B * Ho * Wo, Cout, KH * KW * Cin), dev)
+            L.call("e2e_conv2d_fwd", L.ptr(src0), L.ptr(src1), C1, up, L.ptr(wf), ldf, L.ptr(scale), L.ptr(sh), L.ptr(residual), L.ptr(out),
+                   B, Hs, Ws, Cin, Cout, KH, KW, stride, pad, pad_mode, act, float(isub), float(imul), L.ptr(ws), L.stream())
+        ctx.tune = tune
         ctx.save_for_backward(src0, src1, wb, scale, out)
         ctx.cfg = (B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, act, up, C1, ldb, float(isub), float(imul),
                    bias is not None, residual is not None)
@@ -388,10 +429,17 @@ class _Conv2d(torch.autograd.Function):
             pp = pad if pad_mode == 1 else 0
             direct = pp == 0 and up == 1 and src1 is None
             dxp = torch.empty(B, Cin, Hs + 2 * pp, Ws + 2 * pp, device=dev, dtype=torch.float32, memory_format=CL)
-            nws = L.load().e2e_conv2d_bwd_data_workspace_floats(B, Hs + 2 * pp, Ws + 2 * pp, Cin, KH * KW * Cout, stride)
-            ws2 = torch.empty(nws, device=dev, dtype=torch.float32) if nws else None
-            L.call("e2e_conv2d_bwd_data", L.ptr(dZ), L.ptr(wb), ldb, L.ptr(dxp), B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode,
-                   L.ptr(ws2), st)
+            tune = ctx.tune
+            if tune is not None:
+                ws2 = _gemm_workspace(L.load().e2e_conv_tuned_workspace_floats(B * (Hs + 2 * pp) * (Ws + 2 * pp), Cin), dev)
+                L.call("e2e_conv2d_bwd_data_fused_tuned", L.ptr(dZ), L.ptr(wb), ldb, L.ptr(dxp), B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode,
+                       0, None, 0, None, L.ptr(ws2), tune[0], tune[1], tune[2], st)
+                if tune[2] < 0:
+                    check_streamk(ws2)
+            else:
+                ws2 = _gemm_workspace(L.load().e2e_conv2d_bwd_data_workspace_floats(B, Hs + 2 * pp, Ws + 2 * pp, Cin, KH * KW * Cout, stride), dev)
+                L.call("e2e_conv2d_bwd_data", L.ptr(dZ), L.ptr(wb), ldb, L.ptr(dxp), B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode,
+                       L.ptr(ws2), st)
             if direct:
                 g0 = dxp
             else:

@@ -87,12 +87,12 @@ class _Conv:
                 self.shift = (b - rm * self.scale).contiguous()
         lib = L.load()
         n = lib.e2e_conv2d_splitk_workspace_floats(B * self.Ho * self.Wo, self.Cout, self.KH * self.KW * self.Cin)
-        self.ws_f = torch.empty(n, device=dev, dtype=_f32) if n else None
+        self.ws_f = torch.zeros(n, device=dev, dtype=_f32) if n else None           # zeroed once: its head holds the stream-K hand-off flags
         self.pp = pad if self.pm == 1 else 0
         self.direct = self.pp == 0 and up == 1 and src1 is None
         if self.need_dx:
             n = lib.e2e_conv2d_bwd_data_workspace_floats(B, self.Hs + 2 * self.pp, self.Ws + 2 * self.pp, self.Cin, self.KH * self.KW * self.Cout, stride)
-            self.ws_b = torch.empty(n, device=dev, dtype=_f32) if n else None
+            self.ws_b = torch.zeros(n, device=dev, dtype=_f32) if n else None
             self.dxp = None if self.direct else torch.empty(B, self.Hs + 2 * self.pp, self.Ws + 2 * self.pp, self.Cin, device=dev, dtype=_f32)
         self.ws_w = torch.empty(lib.e2e_conv2d_wgrad_workspace_floats(B, self.Ho, self.Wo, self.Cin, self.Cout, self.KH, self.KW,
                                                                       1 if bias is not None else 0), device=dev, dtype=_f32)

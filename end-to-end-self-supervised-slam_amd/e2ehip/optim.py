@@ -57,7 +57,9 @@ class FusedAdam(torch.optim.Optimizer):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         params = list(params)
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # weight_decay / amsgrad: torch.optim.Adam's remaining defaults, carried (at their off values) so that a state dict written here
+        # is a complete torch.optim.Adam state dict
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
         self._all = params
         self.flat = None
         self.steps = 0              # host-side count of step() CALLS; the step that counts lives on the device (graph replays)
@@ -109,6 +111,64 @@ class FusedAdam(torch.optim.Optimizer):
         self.flat = FlatParams(act)
         self.m = torch.zeros_like(self.flat.data)
         self.v = torch.zeros_like(self.flat.data)
+
+    # ---- torch.optim.Adam-compatible state (train_depth.py:849-863 resumes from `<optimizer>.pth`) --------------------------------
+    def state_dict(self):
+        """The optimiser state in torch.optim.Adam's own format -- {"state": {param index: {"step", "exp_avg", "exp_avg_sq"}},
+        "param_groups": [...]} with indices into the parameter list the optimiser was built on -- so a file written here loads into the
+        reference's Adam and vice versa.  Parameters that never received a gradient carry no state, as in torch."""
+        groups = []
+        start = 0
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != "params"}
+            d["params"] = list(range(start, start + len(g["params"])))
+            start += len(g["params"])
+            groups.append(d)
+        state = {}
+        if self.flat is not None:
+            t = float(self.steps_done())
+            idx = {id(p): i for i, p in enumerate(self._all)}
+            for p, o in zip(self.flat.params, self.flat.offsets):
+                n = p.numel()
+                state[idx[id(p)]] = {"step": torch.tensor(t), "exp_avg": self.m[o:o + n].view_as(p).clone(), "exp_avg_sq": self.v[o:o + n].view_as(p).clone()}
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, state_dict):
+        """Counterpart of torch.optim.Optimizer.load_state_dict for the flat layout: hyper-parameters of the first group, moments and
+        step count.  The flat bucket is laid out over the parameters that carry state (plus, when it exists already, whatever it holds);
+        Adam here keeps ONE step counter for the bucket, torch one per parameter -- they are equal in any file an Adam run wrote."""
+        groups = state_dict["param_groups"]
+        if len(groups) != len(self.param_groups) or sum(len(g["params"]) for g in groups) != len(self._all):
+            raise ValueError("loaded state dict has a different number of parameter groups / parameters")
+        for g, src in zip(self.param_groups, groups):
+            if src.get("weight_decay", 0) or src.get("amsgrad", False) or src.get("maximize", False):
+                raise NotImplementedError("FusedAdam: weight_decay / amsgrad / maximize are not on the reference's path (training_utils.py:23-25)")
+            g.update({k: v for k, v in src.items() if k in ("lr", "betas", "eps")})
+        state = {int(k): v for k, v in state_dict["state"].items()}
+        if not state:
+            return
+        have = [self._all[i] for i in sorted(state) if self._all[i].requires_grad]
+        if self.flat is None:
+            self.prebuild(have)
+        offs = {id(p): o for p, o in zip(self.flat.params, self.flat.offsets)}
+        steps = set()
+        with torch.no_grad():
+            for i, st in state.items():
+                p = self._all[i]
+                if id(p) not in offs:
+                    raise ValueError(f"parameter {i} carries optimiser state but is not part of the flat bucket")
+                o, n = offs[id(p)], p.numel()
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"parameter {i}: state of shape {tuple(st['exp_avg'].shape)} for a parameter of shape {tuple(p.shape)}")
+                self.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+        if len(steps) != 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused optimiser keeps one")
+        self._resident_state()
+        self._counter.fill_(steps.pop() + 1)
+        self._sched_key = None                              # lr / betas may have changed: rebuild the bias-correction table at the next step
+        self._resident_state()
 
     def zero_grad(self, set_to_none=True):
         if self.flat is None:

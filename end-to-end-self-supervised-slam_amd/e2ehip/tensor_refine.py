@@ -59,13 +59,15 @@ class ScaleLayer(torch.nn.Module):
         return x * self.scale
 
 
-def learn_depth_scale(depth_pred, src, tgt, K, T, steps=50, lr=1e-2, init_value=0.5, affine=False, padding_mode="border", use_mask=True):
+def learn_depth_scale(depth_pred, src, tgt, K, T, steps=50, lr=1e-2, init_value=0.5, affine=False, padding_mode="border", use_mask=True,
+                      init_bias=0.0):
     """Learn depth = w * depth_pred (+ b) through the photometric loss (absolute_scale.py:207-240; `affine` = the
-    Conv1x1(1, 1, bias=True) variant).  Returns (w, b, [loss per step]).  d loss / d w = <g, depth_pred>, d loss / d b =
-    sum(g) with g = the fused kernel's d loss / d depth."""
+    Conv1x1(1, 1, bias=True) variant, whose bias torch initialises at random: pass it as init_bias).  The depth network is frozen
+    (its parameters are not in train_params, :223-224), so its prediction is an input.  Returns (w, b, [loss per step]).
+    d loss / d w = <g, depth_pred>, d loss / d b = sum(g) with g = the fused kernel's d loss / d depth."""
     base = L.dev(depth_pred, "depth_pred").detach().contiguous()
     w = torch.nn.Parameter(torch.full((1,), float(init_value), device=base.device))
-    b = torch.nn.Parameter(torch.zeros(1, device=base.device))
+    b = torch.nn.Parameter(torch.full((1,), float(init_bias), device=base.device))
     params = [w, b] if affine else [w]
     opt = FusedAdam(params, lr=lr)
     cur = torch.empty_like(base)
@@ -84,3 +86,16 @@ def learn_depth_scale(depth_pred, src, tgt, K, T, steps=50, lr=1e-2, init_value=
                 prm.grad.copy_(gr)
         opt.step()
     return float(w.data), float(b.data), [float(v[0]) for v in torch.stack(trace).cpu()]
+
+
+def scale_grid_search(depth_pred, src, tgt, K, T, grid, steps=3, lr=1e-2, affine=True, padding_mode="border", use_mask=True, init_bias=0.0):
+    """The outer loop of absolute_scale.py:268-405: for every initial value of SCALE_GRID_SEARCH.grid a FRESH scale layer and a fresh
+    optimiser (`scale_layer_init(init_depth_scale)`, :207-240, :273) are trained for OPTIMIZATION.refinement_steps steps on the same
+    batch.  Returns one record per grid value: {"init", "w", "b", "losses"} -- what the reference prints as "Trainable param after
+    training" for each experiment."""
+    out = []
+    for init in grid:
+        w, b, trace = learn_depth_scale(depth_pred, src, tgt, K, T, steps=steps, lr=lr, init_value=float(init), affine=affine,
+                                        padding_mode=padding_mode, use_mask=use_mask, init_bias=init_bias)
+        out.append({"init": float(init), "w": w, "b": b, "losses": trace})
+    return out

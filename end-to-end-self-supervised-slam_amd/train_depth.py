@@ -132,6 +132,22 @@ class Depth_Estimation:
         assert os.path.isfile(path), "Cannot find {}".format(path)
         self.models["depth"].load_state_dict(torch.load(path, map_location="cpu")["state_dict"])
 
+    def load_optimizer(self):
+        """Resume the optimiser from `<MODEL.load_depth_path>/<OPTIMIZATION.optimizer>.pth` when that file exists (train_depth.py:849-863;
+        torch.optim.Adam's state-dict format, which e2ehip.optim.FusedAdam reads and writes)."""
+        path = os.path.join(os.path.expanduser(str(self.args.MODEL.load_depth_path)), "{}.pth".format(self.args.OPTIMIZATION.optimizer))
+        if os.path.isfile(path):
+            print("Loading Optimizer Weights")
+            self.optimizer.load_state_dict(torch.load(path, map_location=self.device))
+        else:
+            print("Optimizer Not Found. Randomly Initialized")
+
+    def save_optimizer(self):
+        """Writes the file load_optimizer() reads (the reference leaves saving as a TODO, train_depth.py:847)."""
+        path = os.path.join(os.path.expanduser(str(self.args.MODEL.load_depth_path)), "{}.pth".format(self.args.OPTIMIZATION.optimizer))
+        torch.save(self.optimizer.state_dict(), path)
+        return path
+
     def view_reconstruction_init(self):
         a = self.args
         self.backproject_depth = BackprojectDepth(a.OPTIMIZATION.batch_size, a.DATA.height, a.DATA.width)

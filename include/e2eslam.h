@@ -387,13 +387,32 @@ int64_t e2e_conv2d_splitk_workspace_floats(int64_t rows, int cols, int K);
 /* floats of workspace for e2e_conv2d_bwd_data* on an input-gradient domain of (B, Hd, Wd, cols) with K = KH * KW * Cout: the split-K
  * slabs of a stride-1 layer, or the per-(tap, parity class) slabs of the stride-2 class form (4 x 4 x the largest class). */
 int64_t e2e_conv2d_bwd_data_workspace_floats(int B, int Hd, int Wd, int cols, int K, int stride);
-/* Tuning hook (tools/gemm_tune.py): force the workgroup tile (bm x bn in {64x64, 128x64, 128x128, 128x32, 32x128, 32x64,
- * 64x32, 32x32}) and the number of K slices of every following convolution GEMM; bm = 0 restores the built-in choice
- * (a cost model over tile quantisation on 256 CUs, calibrated with that tool).  Query the split-K workspace AFTER forcing. */
-int e2e_conv_gemm_force(int bm, int bn, int ksplit);
-/* tuning hook of the backward-weight GEMM: the number of workgroups its pixel slices are spread over (default 1024);
- * query e2e_conv2d_wgrad_workspace_floats AFTER changing it. */
-int e2e_conv_wgrad_target(int workgroups);
+/* The head of every convolution GEMM workspace (e2e_conv_workspace_flag_floats() floats) holds the hand-off flags of the stream-K
+ * kernels: zero outside a launch (a launch clears what it raised), so the owner zeroes that region ONCE after allocating the buffer.
+ * Its int32 word e2e_conv_streamk_error_index() is raised, and stays raised, if a workgroup ever timed out waiting for a partial tile
+ * (a bounded spin instead of a GPU hang); read it wherever the host synchronises anyway. */
+int e2e_conv_workspace_flag_floats(void);
+int e2e_conv_streamk_error_index(void);
+/* Tuned forms (tools/gemm_tune.py, tests/test_gpu_conv.py): the same operators with the GEMM decomposition given PER CALL -- the
+ * library keeps no mutable tuning state.  tile_m x tile_n in {64x64, 128x64, 128x128, 128x32, 32x128, 32x64, 64x32, 32x32};
+ * ksplit >= 1: K slices (split-K slabs + reduction launch); ksplit < 0: stream-K on -ksplit persistent workgroups (64 x 64 tiles:
+ * equal shares of the flattened (tile, K chunk) space, partial tiles combined in-launch in K order); tile_m == 0: the built-in choice.
+ * workspace: e2e_conv_tuned_workspace_floats(GEMM rows, GEMM columns) floats, flag region zeroed.
+ * e2e_conv2d_bwd_weight_scaled_tuned: the implicit-GEMM backward-weight kernels with `target_workgroups` pixel slices x tiles;
+ * workspace e2e_conv2d_wgrad_tuned_workspace_floats(...). */
+int64_t e2e_conv_tuned_workspace_floats(int64_t rows, int cols);
+int e2e_conv2d_fwd_tuned(const float* src0, const float* src1, int C1, int up, const float* w_fwd, int ld_fwd, const float* scale,
+                         const float* shift, const float* residual, float* out, int B, int Hs, int Ws, int Cin, int Cout, int KH,
+                         int KW, int stride, int pad, int pad_mode, int act, float in_sub, float in_mul, float* workspace, int tile_m,
+                         int tile_n, int ksplit, void* stream);
+int e2e_conv2d_bwd_data_fused_tuned(const float* da, const float* w_bwd, int ld_bwd, float* dxp, int B, int Hs, int Ws, int Cin, int Cout,
+                                    int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, int accumulate, const float* x_in,
+                                    int in_act, const float* pre_add, float* workspace, int tile_m, int tile_n, int ksplit, void* stream);
+int64_t e2e_conv2d_wgrad_tuned_workspace_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int has_bias, int target_workgroups);
+int e2e_conv2d_bwd_weight_scaled_tuned(const float* da, const float* out_scale, const float* src0, const float* src1, int C1, int up,
+                                       float* dw, float* dbias, float* workspace, int B, int Hs, int Ws, int Cin, int Cout, int Ho, int Wo,
+                                       int KH, int KW, int stride, int pad, int pad_mode, int accumulate, float in_sub, float in_mul,
+                                       int target_workgroups, void* stream);
 /* host-only query of that choice: out3 (HOST pointer) = {bm, bn, K slices}. */
 int e2e_conv_gemm_choice(int64_t rows, int cols, int K, int chunk_depth, int allow_split, int* out3_host);
 

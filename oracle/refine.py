@@ -93,7 +93,7 @@ class Refiner:
                 maps = pointfusion.vertex_normal_maps(depths[1][0, 0], Kc[0], poses[0, 1])
                 target_pc = maps["Vg"][maps["valid"]]
                 moved = pointfusion.transform_pointcloud(target_pc, T[0])
-                l3d, _ = knn.knn_points_loss(self.map["points"].detach().unsqueeze(0), moved.unsqueeze(0))
+                l3d, _ = knn.knn_points_loss(self.map["points"].detach().to(moved.dtype).unsqueeze(0), moved.unsqueeze(0))
                 loss = loss + l3d * cfg.three3d_loss_weight
                 rec["knn"] = l3d.item()
             loss.backward()
@@ -146,10 +146,13 @@ class Refiner:
         depths, _ = warp_loss.median_scale(depths, gt_depths)
         cfg = self.cfg
         self.tables = []
+        # the map is an fp32 artefact whatever precision the network runs in (the fp64 variant of this restatement exists to measure how
+        # well-conditioned a trajectory is: tests/test_oracle_conditioning.py)
+        f = lambda t: t.float()
         if self.first_iter:
-            self.map, t = pointfusion.pointfusion_step(self.map, colors[0, 0], depths[0][0, 0], Kc[0], poses[0, 0],
+            self.map, t = pointfusion.pointfusion_step(self.map, f(colors[0, 0]), f(depths[0][0, 0]), f(Kc[0]), f(poses[0, 0]),
                                                        cfg.dist_th, cfg.angle_th, cfg.sigma)
             self.tables.append(t)
-        self.map, t = pointfusion.pointfusion_step(self.map, colors[0, 1], depths[1][0, 0], Kc[0], poses[0, 1],
+        self.map, t = pointfusion.pointfusion_step(self.map, f(colors[0, 1]), f(depths[1][0, 0]), f(Kc[0]), f(poses[0, 1]),
                                                    cfg.dist_th, cfg.angle_th, cfg.sigma)
         self.tables.append(t)

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Phase stamps of k_conv_gemm workgroups (diagnostic build scratch/_stamped/libe2eslam_hip_stamped.so, -DE2E_CONV_STAMPS): when does every
+workgroup of ONE layer1-forward launch start, finish its prologue, its first chunk, its K loop and its epilogue, and on which XCD / CU.
+
+    (cd end-to-end-self-supervised-slam_amd/csrc && for f in *.hip; do hipcc -O3 --offload-arch=gfx950 -fPIC -ffp-contract=off -std=c++17 \
+        -DE2E_CONV_STAMPS -x hip -c $f -o ../../scratch/_stamped/$f.o; done; hipcc --offload-arch=gfx950 -shared -fPIC \
+        -o ../../scratch/_stamped/libe2eslam_hip_stamped.so ../../scratch/_stamped/*.o)
+    python scratch/conv_stamps.py        (on an MI355X; s_memrealtime ticks at 100 MHz = 10 ns)"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "end-to-end-self-supervised-slam_amd")]
+from e2ehip import _lib as L  # noqa: E402
+
+L.LIB_PATH = os.path.join(ROOT, "scratch", "_stamped", "libe2eslam_hip_stamped.so")
+lib = L.load()
+lib.e2e_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+DEV = "cuda:0"
+B, H, W, Cin, Cout = 2, 120, 160, 64, 64
+x = torch.randn(B, H, W, Cin, device=DEV)
+wf = torch.randn(9 * Cin, Cout, device=DEV) * 0.05
+bias = torch.randn(Cout, device=DEV)
+out = torch.empty(B, H, W, Cout, device=DEV)
+ws = torch.zeros(lib.e2e_conv_tuned_workspace_floats(B * H * W, Cout), device=DEV)
+for tile in ((64, 64, 1), (32, 64, 1)):
+    for rep in range(3):
+        L.call("e2e_conv2d_fwd_tuned", L.ptr(x), None, Cin, 1, L.ptr(wf), Cout, None, L.ptr(bias), None, L.ptr(out), B, H, W, Cin, Cout, 3, 3, 1, 1, 0, 1, 0.0, 1.0,
+               L.ptr(ws), tile[0], tile[1], tile[2], L.stream())
+        torch.cuda.synchronize()
+    n = (B * H * W + tile[0] - 1) // tile[0]
+    st = np.zeros(n * 8, dtype=np.uint64)
+    lib.e2e_debug_read_stamps(st.ctypes.data, n * 8)
+    st = st.reshape(n, 8)
+    t0 = st[:, 0].min()
+    rel = (st[:, :6].astype(np.int64) - int(t0)) * 0.01          # us
+    print(f"tile {tile}: {n} workgroups; launch span {rel[:, 5].max():.2f} us")
+    names = ["start", "first loads issued", "prologue done (1st barrier)", "K loop done", "first chunk done", "epilogue stores landed"]
+    for i, nm in enumerate(names):
+        print(f"  {nm:32s} min {rel[:, i].min():7.2f}  median {np.median(rel[:, i]):7.2f}  max {rel[:, i].max():7.2f}")
+    d = rel[:, 3] - rel[:, 2]
+    print(f"  K loop duration  min {d.min():.2f} median {np.median(d):.2f} max {d.max():.2f} us; prologue median {np.median(rel[:, 2] - rel[:, 0]):.2f}; "
+          f"first chunk median {np.median(rel[:, 4] - rel[:, 2]):.2f}; epilogue median {np.median(rel[:, 5] - rel[:, 3]):.2f}")
+    xcc = st[:, 7] & 0xF
+    hw = st[:, 6]
+    cu = (hw >> 8) & 0xF
+    se = (hw >> 13) & 0x7
+    key = xcc * 10000 + se * 100 + cu
+    u, cnt = np.unique(key, return_counts=True)
+    print(f"  distinct (xcc, se, cu) = {len(u)}; workgroups per CU: " + ", ".join(f"{c}:{(cnt == c).sum()}" for c in sorted(set(cnt))))
+    for c in sorted(set(cnt)):
+        sel = np.isin(key, u[cnt == c])
+        print(f"    CUs with {c} workgroups: K loop median {np.median(d[sel]):.2f} us, end of epilogue median {np.median(rel[sel, 5]):.2f} max {rel[sel, 5].max():.2f}")

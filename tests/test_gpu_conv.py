@@ -129,27 +129,55 @@ def test_disparity_head(H, W, act):
 @pytest.mark.parametrize("tile", [(64, 64), (128, 64), (128, 128), (128, 32), (32, 128), (32, 64), (64, 32), (32, 32)], ids=lambda t: f"{t[0]}x{t[1]}")
 @pytest.mark.parametrize("ksplit", [1, 3])
 def test_every_gemm_decomposition(tile, ksplit):
-    """Each workgroup-tile family and split-K forced in turn (e2e_conv_gemm_force) on one layer that all of them fit: forward,
-    backward-data and -- through the same gather -- a stride-2 parity-class backward."""
-    from e2ehip import _lib as L
+    """Each workgroup-tile family and split-K forced in turn (per call: conv.gemm_tuning -> e2e_conv2d_*_tuned) on one layer that all
+    of them fit: forward, backward-data and -- through the same gather -- a stride-2 parity-class backward."""
     from e2ehip import conv
-    lib = L.load()
     g = torch.Generator().manual_seed(tile[0] * 7 + tile[1] + ksplit)
     rnd = lambda *shape: torch.randn(*shape, generator=g)
-    try:
-        for (Cin, Cout, H, W, s) in ((128, 128, 22, 36, 1), (48, 160, 21, 27, 2)):
-            x = rnd(2, Cin, H, W).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-            w = (rnd(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5).to(DEV).requires_grad_(True)
-            scale, shift = (rnd(Cout).abs() + 0.5).to(DEV), rnd(Cout).to(DEV)
-            assert lib.e2e_conv_gemm_force(tile[0], tile[1], ksplit) == 0
+    for (Cin, Cout, H, W, s) in ((128, 128, 22, 36, 1), (48, 160, 21, 27, 2)):
+        x = rnd(2, Cin, H, W).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        w = (rnd(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5).to(DEV).requires_grad_(True)
+        scale, shift = (rnd(Cout).abs() + 0.5).to(DEV), rnd(Cout).to(DEV)
+        with conv.gemm_tuning(tile[0], tile[1], ksplit):
             y = conv.conv2d(x, w, None, s, 1, "zeros", "relu", (scale, shift))
             yr = _ref(x, None, w, None, scale, shift, None, 1, s, 1, "zeros", "relu", None)
             gy = _mask_kinks(rnd(*y.shape).to(DEV), yr, "relu")
             gx, gw = torch.autograd.grad(y, [x, w], gy)
-            lib.e2e_conv_gemm_force(0, 0, 0)
-            gxr, gwr = torch.autograd.grad(yr, [x, w], gy.double())
-            for a, b, name in ((y, yr, "y"), (gx, gxr, "dx"), (gw, gwr, "dw")):
-                e = ((a.double() - b).abs().max() / (b.abs().max() + 1e-30)).item()
-                assert e < 5e-5, f"{name} {Cin}->{Cout} stride {s}: {e:.2e}"
-    finally:
-        lib.e2e_conv_gemm_force(0, 0, 0)
+        gxr, gwr = torch.autograd.grad(yr, [x, w], gy.double())
+        for a, b, name in ((y, yr, "y"), (gx, gxr, "dx"), (gw, gwr, "dw")):
+            e = ((a.double() - b).abs().max() / (b.abs().max() + 1e-30)).item()
+            assert e < 5e-5, f"{name} {Cin}->{Cout} stride {s}: {e:.2e}"
+
+
+@pytest.mark.parametrize("G", [1, 7, 64, 512, 768])
+def test_streamk_decomposition(G):
+    """Stream-K (k_conv_gemm_sk): G persistent workgroups share the (tile, K chunk) space in equal contiguous ranges; partial tiles are
+    handed over through slabs + flags and summed in K order by the workgroup that holds the tile's head.  Every G from one workgroup
+    (all tiles sequentially, no hand-off) to more workgroups than tiles (every tile split several ways): forward with folded BN +
+    ReLU + residual, concat + upsample gather, reflection padding, and backward-data -- against fp64, and bitwise reproducible."""
+    from e2ehip import conv
+    g = torch.Generator().manual_seed(100 + G)
+    rnd = lambda *shape: torch.randn(*shape, generator=g)
+    cases = ((64, 0, 1, 64, 30, 44, "zeros", "relu"), (128, 0, 1, 160, 15, 21, "zeros", None), (32, 32, 2, 64, 24, 40, "reflect", "elu"))
+    for (Cx, Cs, up, Cout, H, W, pm, act) in cases:
+        Cin = Cx + Cs
+        x = rnd(2, Cx, H // up, W // up).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        skip = rnd(2, Cs, H, W).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True) if Cs else None
+        w = (rnd(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5).to(DEV).requires_grad_(True)
+        bias = rnd(Cout).to(DEV) if pm == "reflect" else None
+        bn = ((rnd(Cout).abs() + 0.5).to(DEV), rnd(Cout).to(DEV)) if pm == "zeros" else None
+        res = rnd(2, Cout, H, W).to(DEV).contiguous(memory_format=torch.channels_last) if (pm == "zeros" and act) else None
+        outs = []
+        for rep in range(2):
+            with conv.gemm_tuning(64, 64, -G):
+                y = conv.conv2d(x, w, bias, 1, 1, pm, act, bn, res, skip, up)
+                ins = [x] + ([skip] if Cs else [])
+                yr = _ref(x, skip, w, bias, bn[0] if bn else None, bn[1] if bn else None, res, up, 1, 1, pm, act, None)
+                gy = _mask_kinks(torch.randn(*y.shape, generator=torch.Generator().manual_seed(5)).to(DEV), yr, act)
+                gs = torch.autograd.grad(y, ins, gy)
+            outs.append((y.detach().clone(), [t.clone() for t in gs]))
+        assert torch.equal(outs[0][0], outs[1][0]) and all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+        gr = torch.autograd.grad(yr, ins, gy.double())
+        for a, b, name in [(y, yr, "y")] + [(a, b, f"d_in{i}") for i, (a, b) in enumerate(zip(gs, gr))]:
+            e = ((a.double() - b).abs().max() / (b.abs().max() + 1e-30)).item()
+            assert e < 5e-5, f"G={G} {name} {Cin}->{Cout} {pm}: {e:.2e}"

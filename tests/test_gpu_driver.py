@@ -296,3 +296,32 @@ def test_split_backward_graphs_reproduce_the_single_pass_gradient():
         torch.cuda.synchronize()
         assert torch.equal(flat.grad, ref), (it, float((flat.grad - ref).abs().max()))
     assert ("bwd_late", False) in sp._graphs and "bwd_early" in sp._graphs
+
+
+@pytest.mark.parametrize("head_scale,dtype,tol", [(40.0, torch.float32, 1e-4), (1.0, torch.float64, 1e-4)], ids=["well_conditioned_vs_fp32_oracle", "flat_disparity_vs_fp64_oracle"])
+def test_two_keyframes_free_running_vs_oracle(head_scale, dtype, tol):
+    """FREE-RUNNING: both keyframe pairs of a 3-frame sequence through SLAM.main() -- six refinement steps, the second pair with the 3-D
+    nearest-neighbour loss against the map the first pair fused, no state reset anywhere -- against the oracle's own free run: photometric
+    loss, regulariser, median ratio, 3-D loss and total loss of EVERY step, and the map size.
+
+    This is the comparison round 2 replaced by the teacher-forced test above after it had failed in a mid-round build.  It holds (measured:
+    1e-5 on every quantity), and tests/test_oracle_conditioning.py shows when it has to: with the head weights x 40 the loop is well
+    conditioned (the oracle agrees with its own fp64 evaluation to 5e-6), with the default initialisation it is not (fp32 vs fp64 oracle:
+    1e-3 after five steps) -- there the GPU path is compared with the fp64 oracle, which it follows to ~3e-5 (closer than the fp32 CPU
+    oracle does)."""
+    from test_oracle_conditioning import run_two_keyframes
+    from e2ehip.synthetic import make_sequence
+    from online_adaption import SLAM
+    H, W, L = 64, 96, 3
+    recs = run_two_keyframes(dtype, head_scale)
+    sd = depthnet.random_state_dict(0)
+    sd["decoder.decoder.10.conv.weight"] = sd["decoder.decoder.10.conv.weight"] * head_scale
+    slam = SLAM(_cfg(H, W, L), sequence=make_sequence(L, H, W, seed=7), state_dict=sd)
+    slam.main()
+    log = torch.stack(slam.log).double().numpy()
+    assert log.shape[0] == 6
+    np.testing.assert_allclose(log[:, 1], [r["photometric"] for r in recs], rtol=tol)
+    np.testing.assert_allclose(log[:, 2], [r["reg"] for r in recs], rtol=tol, atol=1e-9)
+    np.testing.assert_allclose(log[:, 3], [r["ratio"] for r in recs], rtol=tol)
+    np.testing.assert_allclose(log[3:, 11], [r["knn"] for r in recs[3:]], rtol=3 * tol)      # mean of ~6000 squared distances of 1e-3 .. 1e-2
+    np.testing.assert_allclose(log[:, 0], [r["loss"] for r in recs], rtol=tol)

@@ -55,6 +55,12 @@ def test_batch_of_two_equals_two_calls(golden):
     torch.testing.assert_close(both, torch.cat([a, b], 0), rtol=1e-5, atol=1e-6)
 
 
+# every parameter gradient of the 480x640 pair against the CPU oracle, as a fraction of the tensor's largest gradient.  Round 2 allowed 1e-3;
+# measured (tests/diag_free_run.py, round 3): 0.5 - 1.4e-5 per tensor at 64x96, all 48 tensors -- the bound below leaves the factor that
+# 25x longer reductions and a handful of ReLU kinks sitting on different sides in two fp32 evaluations need
+GRAD_TOL = 1e-4
+
+
 def test_full_size_pair_forward_backward_vs_oracle():
     """The shipped size: a 480x640 keyframe pair as one batch of 2 through the network, forward and backward, on the GPU (both the
     nn.Module path and the static launch plan of the driver) against the CPU oracle -- this is what exercises the large-grid GEMM
@@ -81,7 +87,7 @@ def test_full_size_pair_forward_backward_vs_oracle():
     for k in keys:
         a, b = params[k].grad.cpu(), sd_o[k].grad
         err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
-        assert err < 1e-3, (k, err)                                 # gradients: 1e-3 of the tensor's max
+        assert err < GRAD_TOL, (k, err)                             # gradients: a fraction of the tensor's max
         torch.testing.assert_close(a.norm(), b.norm(), rtol=1e-4, atol=1e-9)
     # --- launch plan --------------------------------------------------------------------------------------------------
     for p in m.parameters():
@@ -95,4 +101,4 @@ def test_full_size_pair_forward_backward_vs_oracle():
     for k in keys:
         a, b = plan.sink(params[k]).cpu(), sd_o[k].grad
         err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
-        assert err < 1e-3, (k, err)
+        assert err < GRAD_TOL, (k, err)

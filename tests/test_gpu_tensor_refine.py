@@ -56,6 +56,86 @@ def test_oft_reduces_the_loss_and_scale_learning_recovers_the_scale():
     assert tr2[-1] < 0.5 * tr2[0] and np.isfinite([w2, b2]).all()
 
 
+def test_scale_learning_and_grid_search_match_cpu_adam_on_the_oracle_loss():
+    """absolute_scale.py:207-240, :268: for every initial scale of the grid a fresh Conv1x1(1, 1, bias=True) (w, b) on top of the frozen
+    depth prediction, trained by Adam through the photometric loss -- GPU (fused lossgrad + <g, d> / sum(g) + fused Adam) against torch
+    autograd + torch.optim.Adam on the oracle's loss: loss trajectory and the learnt (w, b) of every grid point."""
+    from e2ehip.tensor_refine import scale_grid_search
+    s, t, src, tgt = _pair()
+    base = s["depth"] / 0.8
+    grid, steps, lr, b0 = (0.5, 0.8, 1.1), 6, 1e-2, 0.03
+    got = scale_grid_search(base.to(DEV), src, tgt, t["K"], t["T"], grid, steps=steps, lr=lr, affine=True, init_bias=b0)
+    assert [g["init"] for g in got] == list(grid)
+    for rec in got:
+        w = torch.nn.Parameter(torch.tensor([rec["init"]]))
+        b = torch.nn.Parameter(torch.tensor([b0]))
+        opt = torch.optim.Adam([w, b], lr=lr)
+        ref = []
+        for _ in range(steps):
+            opt.zero_grad()
+            d = base * w + b
+            synth, valid = O.inverse_warp(d, s["src"].permute(0, 3, 1, 2), s["K"], s["invK"], s["T"], "border")[:2]
+            loss = O.masked_photometric_mean(synth, s["tgt"].permute(0, 3, 1, 2), valid, True)[0]
+            loss.backward()
+            opt.step()
+            ref.append(float(loss.detach()))
+        np.testing.assert_allclose(rec["losses"], ref, rtol=1e-4)
+        np.testing.assert_allclose([rec["w"], rec["b"]], [float(w), float(b)], rtol=1e-4, atol=1e-6)
+    assert got[1]["losses"][0] < got[0]["losses"][0] and got[1]["losses"][0] < got[2]["losses"][0]      # 0.8 is the true factor
+
+
+def test_fused_adam_state_round_trip_and_load_optimizer(tmp_path):
+    """train_depth.py:849-863: the optimiser resumes from `<load_depth_path>/Adam.pth`.  FusedAdam writes and reads torch.optim.Adam's
+    state-dict format: (a) save after 3 steps, load into a fresh FusedAdam over equal parameters, one more step on both -> bitwise equal
+    parameters; (b) the same file loads into torch.optim.Adam on the CPU and its next step agrees; (c) Depth_Estimation.load_optimizer."""
+    from e2ehip.optim import FusedAdam
+    g = torch.Generator().manual_seed(4)
+    shapes = [(7, 5), (33,), (4, 3, 3, 3)]
+    grads = [[torch.randn(*sh, generator=g) for sh in shapes] for _ in range(4)]
+
+    def make():
+        gg = torch.Generator().manual_seed(8)
+        ps = [torch.nn.Parameter(torch.randn(*sh, generator=gg).to(DEV)) for sh in shapes]
+        ps.insert(1, torch.nn.Parameter(torch.randn(3, generator=gg).to(DEV), requires_grad=False))        # a frozen parameter in the list
+        return ps
+
+    def step(opt, ps, k):
+        opt.zero_grad()
+        for p, gr in zip([p for p in ps if p.requires_grad], grads[k]):
+            if p.grad is None:
+                p.grad = gr.to(p.device).clone()
+            else:
+                p.grad.copy_(gr.to(p.device))
+        opt.step()
+
+    pa = make()
+    oa = FusedAdam(pa, lr=3e-3)
+    for k in range(3):
+        step(oa, pa, k)
+    path = str(tmp_path / "Adam.pth")
+    torch.save(oa.state_dict(), path)
+    sd = torch.load(path, map_location=DEV)
+    assert sorted(sd["state"]) == [0, 2, 3] and int(sd["state"][0]["step"]) == 3 and sd["param_groups"][0]["params"] == [0, 1, 2, 3]
+    pb = make()
+    with torch.no_grad():
+        for a, b in zip(pa, pb):
+            b.copy_(a)
+    ob = FusedAdam(pb, lr=1.0)                           # the loaded group overrides lr
+    ob.load_state_dict(sd)
+    # (b) torch.optim.Adam reads the same file
+    pc = [torch.nn.Parameter(p.detach().cpu().clone(), requires_grad=p.requires_grad) for p in pa]
+    oc = torch.optim.Adam(pc, lr=1.0)
+    oc.load_state_dict(torch.load(path, map_location="cpu"))
+    step(oa, pa, 3)
+    step(ob, pb, 3)
+    step(oc, pc, 3)
+    torch.cuda.synchronize()
+    for a, b, c in zip(pa, pb, pc):
+        assert torch.equal(a, b)
+        torch.testing.assert_close(a.detach().cpu(), c.detach(), rtol=1e-6, atol=1e-7)
+    assert ob.steps_done() == 4 and ob.param_groups[0]["lr"] == 3e-3
+
+
 def test_map_export_roundtrip(tmp_path):
     from utils.export import load_ply, save_ply
     g = torch.Generator().manual_seed(1)

@@ -59,36 +59,40 @@ def main():
         pp = p if pm == 1 else 0
         dxp = torch.empty(B, H + 2 * pp, W + 2 * pp, Cin, device=DEV)
         rows_f, rows_b = B * Ho * Wo, B * (H + 2 * pp) * (W + 2 * pp)
-        ws = torch.empty(16 * max(rows_f * Cout, rows_b * Cin), device=DEV)
+        ws = torch.zeros(max(lib.e2e_conv_tuned_workspace_floats(rows_f, Cout), lib.e2e_conv_tuned_workspace_floats(rows_b, Cin)), device=DEV)
         gf = 2.0 * B * Ho * Wo * Cout * Cin * k * k / 1e9
+        tune = [0, 0, 0]
 
         def fwd():
-            L.call("e2e_conv2d_fwd", L.ptr(x), L.ptr(skip), Cx, up, L.ptr(wf), ld(Cout), None, L.ptr(bias), None, L.ptr(out), B, H, W, Cin, Cout, k, k, s, p, pm,
-                   2, 0.0, 1.0, L.ptr(ws), st)
+            L.call("e2e_conv2d_fwd_tuned", L.ptr(x), L.ptr(skip), Cx, up, L.ptr(wf), ld(Cout), None, L.ptr(bias), None, L.ptr(out), B, H, W, Cin, Cout, k, k, s, p, pm,
+                   2, 0.0, 1.0, L.ptr(ws), tune[0], tune[1], tune[2], st)
 
         def bwd():
-            L.call("e2e_conv2d_bwd_data", L.ptr(dz), L.ptr(wb), ld(Cin), L.ptr(dxp), B, H, W, Cin, Cout, Ho, Wo, k, k, s, p, pm, L.ptr(ws), st)
+            L.call("e2e_conv2d_bwd_data_fused_tuned", L.ptr(dz), L.ptr(wb), ld(Cin), L.ptr(dxp), B, H, W, Cin, Cout, Ho, Wo, k, k, s, p, pm, 0, None, 0, None,
+                   L.ptr(ws), tune[0], tune[1], tune[2], st)
 
         if which in ("both", "wgrad"):
             dw = torch.empty(Cout, Cin, k, k, device=DEV)
             db = torch.empty(Cout, device=DEV)
             res = []
             for tgt in (256, 384, 512, 768, 1024, 1536, 2048):
-                lib.e2e_conv_wgrad_target(tgt)
-                wsw = torch.empty(lib.e2e_conv2d_wgrad_workspace_floats(B, Ho, Wo, Cin, Cout, k, k, 1), device=DEV)
+                wsw = torch.empty(lib.e2e_conv2d_wgrad_tuned_workspace_floats(B, Ho, Wo, Cin, Cout, k, k, 1, tgt), device=DEV)
 
                 def wg():
-                    L.call("e2e_conv2d_bwd_weight", L.ptr(dz), L.ptr(x), L.ptr(skip), Cx, up, L.ptr(dw), L.ptr(db), L.ptr(wsw), B, H, W, Cin, Cout, Ho, Wo,
-                           k, k, s, p, pm, 0, 0.0, 1.0, st)
+                    L.call("e2e_conv2d_bwd_weight_scaled_tuned", L.ptr(dz), None, L.ptr(x), L.ptr(skip), Cx, up, L.ptr(dw), L.ptr(db), L.ptr(wsw), B, H, W, Cin, Cout,
+                           Ho, Wo, k, k, s, p, pm, 0, 0.0, 1.0, tgt, st)
                 res.append((timeit(wg), tgt))
-            lib.e2e_conv_wgrad_target(1024)
             print(f"{name:10s} wgrad {gf:5.2f} GF | " + " ".join(f"{tgt}:{t:.1f}" for t, tgt in res) + f"  (best {min(res)[1]}: {gf / min(res)[0] * 1e3:.1f} TF/s)", flush=True)
         for tag, fn, ncols, K in (("fwd", fwd, Cout, k * k * Cin), ("bwd", bwd, Cin, k * k * Cout)):
             if which not in ("both", tag):
                 continue
-            lib.e2e_conv_gemm_force(0, 0, 0)
+            tune[:] = [0, 0, 0]
             t_auto = timeit(fn)
             res = []
+            if Cin % 16 == 0 and (Cs == 0 or Cx % 16 == 0) and not (s == 2 and tag == "bwd"):
+                for G in (256, 384, 512, 640, 768):                      # stream-K on G persistent workgroups
+                    tune[:] = [64, 64, -G]
+                    res.append((timeit(fn), 64, 64, -G))
             for bm, bn in TILES:
                 if bn > 32 and ncols <= 16 or bn > 64 and ncols <= 64:
                     continue
@@ -101,12 +105,15 @@ def main():
                         break
                     if S > 1 and s == 2 and tag == "bwd":
                         break
-                    lib.e2e_conv_gemm_force(bm, bn, S)
+                    tune[:] = [bm, bn, S]
                     res.append((timeit(fn), bm, bn, S))
-            lib.e2e_conv_gemm_force(0, 0, 0)
+            tune[:] = [0, 0, 0]
+            if int(ws.view(torch.int32)[lib.e2e_conv_streamk_error_index()]) != 0:
+                print(f"{name} {tag}: STREAM-K TIME-OUT FLAG RAISED", flush=True)
             res.sort()
             best = res[0]
-            line = " ".join(f"{bm}x{bn}/{S}:{t:.1f}" for t, bm, bn, S in res[:6])
+            line = " ".join((f"sk{-S}:{t:.1f}" if S < 0 else f"{bm}x{bn}/{S}:{t:.1f}") for t, bm, bn, S in res[:6])
+            line += "  || stream-K: " + " ".join(f"sk{-S}:{t:.1f}" for t, bm, bn, S in sorted(res, key=lambda r: r[3]) if S < 0)
             print(f"{name:10s} {tag} {gf:5.2f} GF  auto {t_auto:7.1f} us ({gf / t_auto * 1e3:5.1f} TF/s)  best {best[0]:7.1f} us ({gf / best[0] * 1e3:5.1f} TF/s)  | {line}", flush=True)
 
 
