@@ -18,6 +18,8 @@
 // global loads of the next chunk are issued before the current chunk's MFMAs.  Operands are gathered through buffer
 // resources with 32-bit offsets: padding, stride holes and tile tails are out-of-range offsets that the hardware
 // answers with zeros, so the K loop has no branches and no 64-bit address arithmetic.
+#include <type_traits>
+
 #include "e2e_common.h"
 
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -194,6 +196,79 @@ __device__ __forceinline__ void epilogue_block(const ConvArgs& a, const EpiRsrc&
 // ran at the L1 request rate, not the MFMA rate: time did not react to chunk depth, read scheduling or warp
 // specialisation -- profiles/r01_notes.md.)  The LDS tile stays k-major for conflict-free MFMA operand reads; its row
 // stride is padded so that the transposing stores of 4*CB/16 lanes per row spread over banks.
+// ---- branch-free gather offsets (VEC == 4 loaders of k_conv_gemm / k_conv_gemm_sk) ---------------------------------------------------
+// A slot's byte offset of tap (kh, kw) is SEPARABLE: row part (image, source row) + column part (source column, channel quad).  Both
+// parts are tabulated per slot for the <= 3 values of kh and kw when a tile starts -- stride, zero / reflection padding, the transposed
+// (backward-data) index map with its stride holes, the x2 upsample and the two sources of a concat layer all resolved there, once --
+// so that moving to the next tap inside the K loop is two selects and one add per source, with no branches.  A part that reads a
+// structural zero is a large constant (row: 2^31, column: 2^30): any sum containing one lies beyond num_records (operands stay below
+// 2^30 bytes, checked by the host) and the buffer load returns 0.
+// (The first form re-derived the coordinates of every tap in the loop: ~90 VALU + ~115 SALU instructions per chunk in a dozen
+// exec-masked basic blocks, none of which the scheduler could move under the 16 MFMAs of the chunk -- the loop spent as long outside
+// its matrix instructions as inside them: round-3 disassembly and phase stamps.)
+#define TAP_ROW_ZERO 0x80000000u
+#define TAP_COL_ZERO 0x40000000u
+
+template <bool TRANSPOSED>
+__device__ __forceinline__ int axis_src(const ConvArgs& a, int d, int k, int n_src) {      // source coordinate along one axis, -1: structural zero
+    if (!TRANSPOSED) {
+        const int s = d * a.stride + k - a.pad;
+        if (a.pad_mode == 1) return reflect1(s, n_src);
+        return (s >= 0 && s < n_src) ? s : -1;
+    } else {
+        const int t = d + a.off - k;
+        if (t < 0) return -1;
+        if (a.stride == 2) return ((t & 1) == 0 && (t >> 1) < n_src) ? (t >> 1) : -1;
+        return t < n_src ? t : -1;
+    }
+}
+
+// GEMM row n -> (image, row, column) of an (Hc x Wc) lattice without integer division: reciprocal multiplication in fp32 + exact fix-up
+// (n < 2^24, checked by the host).  A 64-bit division per slot was a third of the kernels' prologue.
+__device__ __forceinline__ void decode_row(int n, int hw, int Wc, float inv_hw, float inv_w, int& b, int& y, int& x) {
+    b = (int)((float)n * inv_hw);
+    b -= (b * hw > n) ? 1 : 0;
+    b += ((b + 1) * hw <= n) ? 1 : 0;
+    const int r = n - b * hw;
+    y = (int)((float)r * inv_w);
+    y -= (y * Wc > r) ? 1 : 0;
+    y += ((y + 1) * Wc <= r) ? 1 : 0;
+    x = r - y * Wc;
+}
+
+template <bool TRANSPOSED, int A_PER>
+struct TapTable {
+    unsigned r0[A_PER][3], c0[A_PER][3], r1[A_PER][3], c1[A_PER][3];
+
+    // slot j gathers output-domain pixel (b, yd, xd) (live == false: a row past the end of the GEMM), channel quad `quad`.
+    // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): row indices < 2^24 and row pitches in bytes < 2^24 (operands < 1 GB)
+    __device__ __forceinline__ void init(const ConvArgs& a, int j, bool live, int b, int yd, int xd, int quad) {
+        const int sh = a.up >> 1, Hl = a.Hs >> sh, Wl = a.Ws >> sh, C2 = a.Cin - a.C1;
+        const unsigned pitch0 = (unsigned)(Wl * a.C1 * 4), pitch1 = (unsigned)(a.Ws * C2 * 4), px0 = (unsigned)(a.C1 * 4), px1 = (unsigned)(C2 * 4);
+        const unsigned row0 = (unsigned)(b * Hl), row1 = (unsigned)(b * a.Hs), q16 = (unsigned)quad * 16u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int ys = (live && k < a.KH) ? axis_src<TRANSPOSED>(a, yd, k, a.Hs) : -1;
+            const int xs = (live && k < a.KW) ? axis_src<TRANSPOSED>(a, xd, k, a.Ws) : -1;
+            r0[j][k] = ys >= 0 ? __umul24(row0 + (unsigned)(ys >> sh), pitch0) : TAP_ROW_ZERO;
+            r1[j][k] = ys >= 0 ? __umul24(row1 + (unsigned)ys, pitch1) : TAP_ROW_ZERO;
+            c0[j][k] = xs >= 0 ? __umul24((unsigned)(xs >> sh), px0) + q16 : TAP_COL_ZERO;
+            c1[j][k] = xs >= 0 ? __umul24((unsigned)xs, px1) + q16 : TAP_COL_ZERO;
+        }
+    }
+    // (selection by bit masks of the wave-uniform tap index: written as `k == 0 ? t[0] : ...` hipcc turns the tables into a scratch array
+    // indexed at run time -- eight scratch loads per chunk)
+    __device__ __forceinline__ void tap(int kh, int kw, unsigned (&off0)[A_PER], unsigned (&off1)[A_PER]) const {
+        const unsigned h0 = kh == 0 ? ~0u : 0u, h1 = kh == 1 ? ~0u : 0u, h2 = kh >= 2 ? ~0u : 0u;
+        const unsigned w0 = kw == 0 ? ~0u : 0u, w1 = kw == 1 ? ~0u : 0u, w2 = kw >= 2 ? ~0u : 0u;
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            off0[j] = ((r0[j][0] & h0) | (r0[j][1] & h1) | (r0[j][2] & h2)) + ((c0[j][0] & w0) | (c0[j][1] & w1) | (c0[j][2] & w2));
+            off1[j] = ((r1[j][0] & h0) | (r1[j][1] & h1) | (r1[j][2] & h2)) + ((c1[j][0] & w0) | (c1[j][1] & w1) | (c1[j][2] & w2));
+        }
+    }
+};
+
 // XCD-aware workgroup order (MI355X: 8 XCDs, each with its own 4 MB L2; workgroups are dealt to them round-robin in launch order, so
 // consecutive ids land on DIFFERENT L2s).  Tiles that are neighbours in the image re-read each other's input rows (3x3 taps) and all
 // column tiles / K slices of one row tile read the same rows: this remap hands every XCD a CONTIGUOUS range of the launch's linear ids
@@ -203,6 +278,19 @@ __device__ __forceinline__ void epilogue_block(const ConvArgs& a, const EpiRsrc&
 __device__ __forceinline__ unsigned xcd_contiguous(unsigned id, unsigned n) {
     const unsigned q = n >> 3, r = n & 7u, k = id & 7u, j = id >> 3;
     return k * q + (k < r ? k : r) + j;
+}
+
+// Static wave priority by launch order.  The workgroups that share a CU run the same program and, with the matrix pipe arbitrated fairly
+// between them, fall into LOCKSTEP: all of them multiply at the same time (n x 1024 cycles per chunk, interleaved) and then all of them
+// stage / synchronise / read LDS at the same time with the pipe idle (~1570 cycles) -- measured per chunk: 0.66 us + 0.43 us x n
+// (scratch/conv_stamps.py).  Workgroups id, id + 256, id + 512 ... are the ones that end up on one CU (256 CUs, round-robin dispatch):
+// giving them DIFFERENT priorities lets the highest one run its MFMA chain unimpeded while the others fill its staging phase, and the
+// phases stay interleaved.  Speed only.
+__device__ __forceinline__ void set_wave_priority(unsigned linear_block_id) {
+    const unsigned p = (linear_block_id >> 8) & 3u;
+    if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 3) __builtin_amdgcn_s_setprio(3);
 }
 
 #ifdef E2E_CONV_STAMPS          // diagnostic build only (scratch/conv_stamps.py): s_memtime / s_memrealtime stamps of every workgroup's phases
@@ -225,6 +313,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     __shared__ float As[2][CB][BM + APAD];
     __shared__ float Bs[2][CB][BN];
     STAMP(0);
+    set_wave_priority(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     // parity-class form (transposed gather, stride 2): this workgroup's class, its pixel sub-lattice and its tap subset
@@ -269,19 +358,26 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         ab[j] = ayd[j] = axd[j] = 0;
         if (arow_ok[j]) {
             const int hw = Hc * Wc;
-            ab[j] = (int)(an / hw);
-            const int r = (int)(an - (int64_t)ab[j] * hw);
-            ayd[j] = r / Wc;
-            axd[j] = r - ayd[j] * Wc;
+            if (Ntot < (1 << 24)) {
+                decode_row((int)an, hw, Wc, 1.0f / (float)hw, 1.0f / (float)Wc, ab[j], ayd[j], axd[j]);
+            } else {
+                ab[j] = (int)(an / hw);
+                const int r = (int)(an - (int64_t)ab[j] * hw);
+                ayd[j] = r / Wc;
+                axd[j] = r - ayd[j] * Wc;
+            }
             if (CLS) { ayd[j] = 2 * ayd[j] + py; axd[j] = 2 * axd[j] + px; }
         }
     }
     const int sh = a.up >> 1;                                // up is 1 or 2: source coordinate = full-res coordinate >> sh
     const int Hl = a.Hs >> sh, Wl = a.Ws >> sh, C2 = a.Cin - a.C1;
 
-    f4v areg[A_PER];
-    float areg1[A_PER];
-    f4v breg[B_PER];
+    // staging registers: TWO sets -- the global loads of chunk c + 2 are issued while chunk c is multiplied and chunk c + 1 waits in the
+    // other set for its turn to be written to LDS.  (One set = loads one chunk ahead left every workgroup waiting ~1.5 us per chunk for
+    // fabric-served loads against 0.43 us of MFMA work: round-3 phase stamps, scratch/conv_stamps.py.)
+    f4v areg[2][A_PER];
+    float areg1[2][A_PER];
+    f4v breg[2][B_PER];
 
     // VEC == 4.  Everything the gather needs per chunk is ONE select and ONE buffer load per slot:
     //  * operands are addressed through buffer resources with 32-bit byte offsets (tensors < 2 GB, checked by the
@@ -296,24 +392,21 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0, (int)(a.src1 ? a.bytes1 : 0), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.bytesw, 0x00020000);
     const int cpt = (VEC == 4) ? a.Cin / CB : 1;           // chunks per tap
-    int ld_kh = 0, ld_kw = 0, ld_cc = 0;                     // state of the LOAD stream (runs one chunk ahead)
+    int ld_kh = 0, ld_kw = 0, ld_cc = 0;                     // state of the LOAD stream (runs two chunks ahead)
     unsigned off0[A_PER], off1[A_PER];                       // byte offsets of (tap pixel, this thread's quad) in src0 / src1
-    auto set_tap = [&]() {
-        const bool tap_ok = ld_kh < a.KH;                  // (class form: kh walks kh0, kh0 + 2, ...)
+    TapTable<TRANSPOSED, A_PER> taps;                        // (unused by the scalar VEC == 1 loader)
+    if (VEC == 4) {
 #pragma unroll
-        for (int j = 0; j < A_PER; ++j) {
-            int ys = 0, xs = 0;
-            const bool ok = tap_ok && arow_ok[j] && tap_coord<TRANSPOSED>(a, ayd[j], axd[j], ld_kh, ld_kw, ys, xs);
-            const unsigned p0 = (unsigned)((ab[j] * Hl + (ys >> sh)) * Wl + (xs >> sh)) * (unsigned)a.C1 + (unsigned)(akq * 4);
-            const unsigned p1 = (unsigned)((ab[j] * a.Hs + ys) * a.Ws + xs) * (unsigned)C2 + (unsigned)(akq * 4);
-            off0[j] = ok ? p0 * 4u : OOB;
-            off1[j] = ok ? p1 * 4u : OOB;
-        }
-    };
-    auto next_tap = [&]() {
-        ld_cc = 0;
-        ld_kw += kstep;
-        if (ld_kw >= a.KW) { ld_kw = kw0; ld_kh += kstep; }
+        for (int j = 0; j < A_PER; ++j) taps.init(a, j, arow_ok[j], ab[j], ayd[j], axd[j], akq);
+    }
+    auto set_tap = [&]() { if (VEC == 4) taps.tap(ld_kh, ld_kw, off0, off1); };
+    auto advance_tap = [&]() {                               // branch-free: selects on wave-uniform values (taps past the last one of a
+        const bool w1 = ++ld_cc == cpt;                      // slice are read but never multiplied)
+        ld_cc = w1 ? 0 : ld_cc;
+        ld_kw += w1 ? kstep : 0;
+        const bool w2 = ld_kw >= a.KW;
+        ld_kw = w2 ? kw0 : ld_kw;
+        ld_kh += w2 ? kstep : 0;
         set_tap();
     };
     unsigned boff[B_PER];                                    // B tile: fixed per-thread offset, the chunk rides in soffset
@@ -332,7 +425,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         set_tap();
     }
 
-    auto load_chunk = [&](int chunk) {
+    auto load_chunk = [&](int chunk, int set) {
         const int kbase = chunk * CB;
         if (VEC == 4) {
             const int cbase = ld_cc * CB;                    // wave-uniform: the whole chunk lies on one side of the concat split
@@ -342,11 +435,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
             const int soff = (use0 ? cbase : cbase - a.C1) * 4;
 #pragma unroll
             for (int j = 0; j < A_PER; ++j)
-                areg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs, use0 ? off0[j] : off1[j], soff, 0));
-            if (++ld_cc == cpt) next_tap();
+                areg[set][j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs, use0 ? off0[j] : off1[j], soff, 0));
+            advance_tap();
 #pragma unroll
             for (int j = 0; j < B_PER; ++j)
-                breg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsw, boff[j], krow * a.ldw * 4, 0));
+                breg[set][j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsw, boff[j], krow * a.ldw * 4, 0));
         } else {
 #pragma unroll
             for (int j = 0; j < A_PER; ++j) {
@@ -360,33 +453,33 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
                     if (tap_coord<TRANSPOSED>(a, ayd[j], axd[j], kh, kw, ys, xs))
                         v = (a.src0[(((int64_t)ab[j] * a.Hs + ys) * a.Ws + xs) * a.Cin + ci] - a.in_sub) * a.in_mul;
                 }
-                areg1[j] = v;
+                areg1[set][j] = v;
             }
 #pragma unroll
             for (int j = 0; j < B_PER; ++j) {
                 const int kr = (tid + j * NT) / (BN / 4);
-                breg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsw, (kbase + kr < K) ? boff[j] : OOB, kbase * a.ldw * 4, 0));
+                breg[set][j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsw, (kbase + kr < K) ? boff[j] : OOB, kbase * a.ldw * 4, 0));
             }
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, int set) {
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
             if (VEC == 4) {
-                if (tid + j * NT >= A_CNT) continue;
+                if (A_CNT % NT != 0 && tid + j * NT >= A_CNT) continue;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) As[buf][akq * 4 + e][arow[j]] = areg[j][e];
+                for (int e = 0; e < 4; ++e) As[buf][akq * 4 + e][arow[j]] = areg[set][j][e];
             } else {
                 const int kq = akq + j * (NT / BM);
-                if (kq < KQ) As[buf][kq][arow[j]] = areg1[j];
+                if (kq < KQ) As[buf][kq][arow[j]] = areg1[set][j];
             }
         }
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
             const int idx = tid + j * NT;
-            if (idx >= B_CNT) continue;
+            if (B_CNT % NT != 0 && idx >= B_CNT) continue;
             const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
-            *(f4v*)&Bs[buf][kr][cq * 4] = breg[j];
+            *(f4v*)&Bs[buf][kr][cq * 4] = breg[set][j];
         }
     };
 
@@ -399,16 +492,22 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[u][t][r] = 0.f;
 
     if (cbeg < cend) {
-        load_chunk(cbeg);
+        load_chunk(cbeg, 0);
         STAMP(1);
-        store_chunk(0);
+        if (VEC == 4 || cbeg + 1 < cend) load_chunk(cbeg + 1, 1);
+        store_chunk(0, 0);
     }
     __syncthreads();
     STAMP(2);
     const int arow_l = wm * TM * 32 + (lane & 31), khalf = lane >> 5;
-    for (int c = cbeg; c < cend; ++c) {
-        const int buf = (c - cbeg) & 1;
-        if (c + 1 < cend) load_chunk(c + 1);                // global loads in flight under the MFMAs below
+    // one K chunk: chunk c (in LDS buffer `BUF`) is multiplied while the loads of chunk c + 2 go to register set BUF (free: its chunk c
+    // is in LDS) and chunk c + 1 -- loaded one iteration earlier into set BUF ^ 1 -- is written to the other LDS buffer afterwards
+    auto chunk_step = [&](int c, auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
+        // VEC == 4: loads and stores are UNCONDITIONAL (chunks past the end of the slice are fetched -- out-of-range offsets return zeros --
+        // and written to the LDS buffer nobody reads any more): the chunk is one basic block and the scheduler may place the staging
+        // instructions between the MFMAs
+        if (VEC == 4 || c + 2 < cend) load_chunk(c + 2, buf);
         // operand fragments of the WHOLE chunk are read into registers first, the MFMAs follow with counted LDS waits: hipcc's own
         // schedule of the fused loop was read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs per k-pair on ONE register set, i.e. every pair of MFMAs
         // waited for a fresh LDS round trip (~190 cycles per 128 cycles of matrix work: the kernels ran at half the MFMA rate with
@@ -433,9 +532,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x100, KH2 * (TM + TN) / 2, 0);     // all LDS reads of the batch (ds_read2: two values each) ...
             __builtin_amdgcn_sched_group_barrier(0x008, KH2 * TM * TN, 0);           // ... ahead of its MFMAs
         }
-        if (c + 1 < cend) store_chunk(buf ^ 1);
+        if (VEC == 4 || c + 1 < cend) store_chunk(buf ^ 1, buf ^ 1);
         __syncthreads();
         if (c == cbeg) STAMP(4);
+    };
+    for (int c = cbeg; c < cend; c += 2) {
+        chunk_step(c, std::integral_constant<int, 0>{});
+        if (c + 1 < cend) chunk_step(c + 1, std::integral_constant<int, 1>{});
     }
     STAMP(3);
 
@@ -555,6 +658,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_sk(ConvArgs a, SkArgs s) {
     __shared__ float As[2][CB][BM + 1];
     __shared__ float Bs[2][CB][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+    set_wave_priority(blockIdx.x);
+    STAMP(0);
+    int stamp_piece = 0;
+    (void)stamp_piece;
     const int g = (int)xcd_contiguous(blockIdx.x, gridDim.x);          // consecutive iteration ranges (neighbouring tiles) share an XCD's L2
     const int64_t Ntot = (int64_t)a.B * a.Hd * a.Wd;
     constexpr unsigned OOB = 0x80000000u;
@@ -563,6 +670,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_sk(ConvArgs a, SkArgs s) {
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.bytesw, 0x00020000);
     const int sh = a.up >> 1, Hl = a.Hs >> sh, Wl = a.Ws >> sh, C2 = a.Cin - a.C1, cpt = a.Cin / CB, hw = a.Hd * a.Wd;
     const int akq = tid % KQ, arow_l = wm * 32 + (lane & 31), khalf = lane >> 5;
+    const float inv_hw = 1.0f / (float)hw, inv_wd = 1.0f / (float)a.Wd;
     int64_t it = s.I * g / s.G;
     const int64_t it_end = s.I * (g + 1) / s.G;
     while (it < it_end) {
@@ -581,10 +689,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_sk(ConvArgs a, SkArgs s) {
             arow_ok[j] = an < Ntot;
             ab[j] = ayd[j] = axd[j] = 0;
             if (arow_ok[j]) {
-                ab[j] = (int)(an / hw);
-                const int r = (int)(an - (int64_t)ab[j] * hw);
-                ayd[j] = r / a.Wd;
-                axd[j] = r - ayd[j] * a.Wd;
+                if (Ntot < (1 << 24)) {
+                    decode_row((int)an, hw, a.Wd, inv_hw, inv_wd, ab[j], ayd[j], axd[j]);
+                } else {
+                    ab[j] = (int)(an / hw);
+                    const int r = (int)(an - (int64_t)ab[j] * hw);
+                    ayd[j] = r / a.Wd;
+                    axd[j] = r - ayd[j] * a.Wd;
+                }
             }
         }
         unsigned boff[B_PER];
@@ -595,27 +707,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_sk(ConvArgs a, SkArgs s) {
         }
         int ld_kh, ld_kw, ld_cc;
         unsigned off0[A_PER], off1[A_PER];
-        auto set_tap = [&]() {
-            const bool tap_ok = ld_kh < a.KH;
+        TapTable<TRANSPOSED, A_PER> taps;
 #pragma unroll
-            for (int j = 0; j < A_PER; ++j) {
-                int ys = 0, xs = 0;
-                const bool ok = tap_ok && arow_ok[j] && tap_coord<TRANSPOSED>(a, ayd[j], axd[j], ld_kh, ld_kw, ys, xs);
-                const unsigned p0 = (unsigned)((ab[j] * Hl + (ys >> sh)) * Wl + (xs >> sh)) * (unsigned)a.C1 + (unsigned)(akq * 4);
-                const unsigned p1 = (unsigned)((ab[j] * a.Hs + ys) * a.Ws + xs) * (unsigned)C2 + (unsigned)(akq * 4);
-                off0[j] = ok ? p0 * 4u : OOB;
-                off1[j] = ok ? p1 * 4u : OOB;
-            }
-        };
+        for (int j = 0; j < A_PER; ++j) taps.init(a, j, arow_ok[j], ab[j], ayd[j], axd[j], akq);
         {
             const int t0 = cb / cpt;
             ld_kh = t0 / a.KW;
             ld_kw = t0 - ld_kh * a.KW;
             ld_cc = cb - t0 * cpt;
-            set_tap();
+            taps.tap(ld_kh, ld_kw, off0, off1);
         }
-        f4v areg[A_PER], breg[B_PER];
-        auto load_chunk = [&]() {
+        f4v areg[2][A_PER], breg[2][B_PER];                  // two staging sets: loads run two chunks ahead (see k_conv_gemm)
+        auto load_chunk = [&](int set) {
             const int cbase = ld_cc * CB;
             const int krow = (ld_kh * a.KW + ld_kw) * a.Cin + cbase;
             const bool use0 = cbase < a.C1;
@@ -623,36 +726,41 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_sk(ConvArgs a, SkArgs s) {
             const int soff = (use0 ? cbase : cbase - a.C1) * 4;
 #pragma unroll
             for (int j = 0; j < A_PER; ++j)
-                areg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs, use0 ? off0[j] : off1[j], soff, 0));
-            if (++ld_cc == cpt) {
-                ld_cc = 0;
-                if (++ld_kw >= a.KW) { ld_kw = 0; ++ld_kh; }
-                set_tap();
+                areg[set][j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs, use0 ? off0[j] : off1[j], soff, 0));
+            {                                                   // next chunk's tap: selects on wave-uniform values, no branches
+                const bool w1 = ++ld_cc == cpt;
+                ld_cc = w1 ? 0 : ld_cc;
+                ld_kw += w1 ? 1 : 0;
+                const bool w2 = ld_kw >= a.KW;
+                ld_kw = w2 ? 0 : ld_kw;
+                ld_kh += w2 ? 1 : 0;
+                taps.tap(ld_kh, ld_kw, off0, off1);
             }
 #pragma unroll
             for (int j = 0; j < B_PER; ++j)
-                breg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsw, boff[j], krow * a.ldw * 4, 0));
+                breg[set][j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsw, boff[j], krow * a.ldw * 4, 0));
         };
-        auto store_chunk = [&](int buf) {
+        auto store_chunk = [&](int buf, int set) {
 #pragma unroll
             for (int j = 0; j < A_PER; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) As[buf][akq * 4 + e][arow[j]] = areg[j][e];
+                for (int e = 0; e < 4; ++e) As[buf][akq * 4 + e][arow[j]] = areg[set][j][e];
 #pragma unroll
             for (int j = 0; j < B_PER; ++j) {
                 const int idx = tid + j * NT, kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
-                *(f4v*)&Bs[buf][kr][cq * 4] = breg[j];
+                *(f4v*)&Bs[buf][kr][cq * 4] = breg[set][j];
             }
         };
         f16v acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        load_chunk();
-        store_chunk(0);
+        load_chunk(0);
+        load_chunk(1);                                          // (unconditional, like every load / store of the loop: see k_conv_gemm)
+        store_chunk(0, 0);
         __syncthreads();
-        for (int c = cb; c < ce; ++c) {
-            const int buf = (c - cb) & 1;
-            if (c + 1 < ce) load_chunk();
+        auto chunk_step = [&](int c, auto buf_c) {
+            constexpr int buf = decltype(buf_c)::value;
+            load_chunk(buf);
             float av[CB / 2], bv[CB / 2];                       // the chunk's fragments first, then the MFMAs (see k_conv_gemm)
 #pragma unroll
             for (int kk = 0; kk < CB / 2; ++kk) {
@@ -661,13 +769,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_sk(ConvArgs a, SkArgs s) {
             }
 #pragma unroll
             for (int kk = 0; kk < CB / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, CB / 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, CB / 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, CB / 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, CB / 2, 0);
-            if (c + 1 < ce) store_chunk(buf ^ 1);
+            store_chunk(buf ^ 1, buf ^ 1);
             __syncthreads();
+        };
+        if (stamp_piece == 0) STAMP(1);
+        for (int c = cb; c < ce; c += 2) {
+            chunk_step(c, std::integral_constant<int, 0>{});
+            if (c + 1 < ce) chunk_step(c + 1, std::integral_constant<int, 1>{});
         }
+        if (stamp_piece == 0) STAMP(2);
         // ---- what to do with the accumulator ------------------------------------------------------------------------------------
         const unsigned sl_off = (unsigned)((wave * 4 * 64 + lane) * 16);         // this lane's first 16-byte quad inside a slab
         if (cb != 0) {
@@ -690,6 +802,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_sk(ConvArgs a, SkArgs s) {
         } else {
             if (ce != s.C) {
                 // the tile's head: this workgroup finishes the tile with the pieces of g + 1, g + 2, ... (increasing K)
+                STAMP(4);
                 const int64_t tile_end = (int64_t)(tile + 1) * s.C;
                 int h_last = g;
                 for (int h = g + 1; h < s.G && s.I * h / s.G < tile_end; ++h) h_last = h;
@@ -705,6 +818,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_sk(ConvArgs a, SkArgs s) {
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                STAMP(5);
                 for (int h = g + 1; h <= h_last; ++h) {
                     const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(s.slabs + (int64_t)h * (BM * BN)), 0, BM * BN * 4, 0x00020000);
                     f4v t[4];
@@ -721,8 +835,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_sk(ConvArgs a, SkArgs s) {
             const EpiRsrc er = make_epi_rsrc<TRANSPOSED>(a);
             epilogue_block<TRANSPOSED>(a, er, acc, c0 + wn * 32 + (lane & 31), n0 + wm * 32 + 4 * khalf, Ntot);
         }
+        if (stamp_piece == 0) STAMP(3);
+        ++stamp_piece;
         it += ce - cb;
     }
+#ifdef E2E_CONV_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(6);
+    if (threadIdx.x == 0) g_stamps[blockIdx.x * 8 + 7] = (unsigned long long)stamp_piece;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -976,6 +1097,7 @@ struct WgradArgs {
 // and the same input rows -- they run on one XCD, back to back
 #define WGRAD_BLOCK_IDS                                                                                                                   \
     unsigned bx, by, bz;                                                                                                                  \
+    set_wave_priority(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));                                                   \
     {                                                                                                                                     \
         const unsigned lin = xcd_contiguous(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z); \
         bx = lin % gridDim.x;                                                                                                             \
@@ -1137,39 +1259,31 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm(WgradArgs a) {
 // out-of-range offsets), no integer divisions in the chunk loop, CB pixels per chunk.  A concat layer reads its two
 // sources through two resources: lanes of one load instruction span columns on both sides of the split, and a
 // resource is wave-uniform, so each slot issues one load per source with the foreign lanes out of range.
-template <int WM, int WN, int CB>
+template <int WM, int WN, int CB, bool TWO>
 __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
     constexpr int BM = 32 * WM, BN = 32 * WN, NT = 256;     // WM x WN = 4 waves, one 32x32 accumulator each
     constexpr int A_CNT = CB * (BM / 4), B_CNT = CB * (BN / 4);
-    constexpr int A_PER = (A_CNT + NT - 1) / NT, B_PER = (B_CNT + NT - 1) / NT;
+    constexpr int A_PER = A_CNT / NT, B_PER = B_CNT / NT;
+    static_assert(A_CNT % NT == 0 && B_CNT % NT == 0, "tile / thread-count mismatch");
     __shared__ float As[2][CB][BM];
     __shared__ float Bs[2][CB][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     WGRAD_BLOCK_IDS
     const int m0 = by * BM, nn0 = bx * BN;
-    const int64_t P = (int64_t)a.B * a.Ho * a.Wo;
-    const int64_t p0 = (int64_t)bz * a.pix_per_slice;
-    const int64_t p1 = (p0 + a.pix_per_slice < P) ? p0 + a.pix_per_slice : P;
-    const int npix = (p1 > p0) ? (int)(p1 - p0) : 0;
+    const int P = a.B * a.Ho * a.Wo;                          // < 2^24 (host): pixel indices are exact in fp32
+    const int p0 = (int)((int64_t)bz * a.pix_per_slice);
+    const int p1 = (p0 + a.pix_per_slice < P) ? (int)(p0 + a.pix_per_slice) : P;
+    const int npix = (p1 > p0) ? p1 - p0 : 0;
     const int nchunks = (npix + CB - 1) / CB;
     const int sh = a.up >> 1;
     const int Hl = a.Hs >> sh, Wl = a.Ws >> sh, C2 = a.Cin - a.C1;
     const int Kconv = a.KH * a.KW * a.Cin;
     constexpr unsigned OOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, (int)(P * a.Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, (int)((int64_t)P * a.Cout * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)((int64_t)a.B * Hl * Wl * a.C1 * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0,
                                                                          (int)(a.src1 ? (int64_t)a.B * a.Hs * a.Ws * C2 * 4 : 0), 0x00020000);
-    // which source do this workgroup's columns read?  0: src0 only, 1: src1 only (the tile lies inside one tap on one side
-    // of the concat split), 2: both (one load per source and slot)
-    int src_mode = 0;
-    if (a.src1 != nullptr) {
-        const int c_lo = min(nn0, Kconv - 1), c_hi = min(nn0 + BN - 1, Kconv - 1);
-        const int t_lo = c_lo / a.Cin, t_hi = c_hi / a.Cin;
-        const bool lo0 = (c_lo - t_lo * a.Cin) < a.C1, hi0 = (c_hi - t_hi * a.Cin) < a.C1;
-        src_mode = (t_lo == t_hi && lo0 == hi0) ? (lo0 ? 0 : 1) : 2;
-    }
 
     // A (dZ) slots: row kr of the chunk, cout quad -- the chunk rides in soffset
     int a_kr[A_PER];
@@ -1179,92 +1293,92 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
         const int idx = tid + j * NT;
         a_kr[j] = idx / (BM / 4);
         const int m = m0 + (idx - a_kr[j] * (BM / 4)) * 4;
-        a_off[j] = (idx < A_CNT && m < a.Cout) ? (unsigned)(a_kr[j] * a.Cout + m) * 4u : OOB;      // Cout % 4 == 0
+        a_off[j] = (m < a.Cout) ? (unsigned)(a_kr[j] * a.Cout + m) * 4u : OOB;      // Cout % 4 == 0
     }
-    // B (gathered input) slots: pixel row kr of the chunk, column quad -> (tap, ci) decoded once; the pixel advances by CB
-    int b_kr[B_PER], b_kh[B_PER], b_kw[B_PER], b_ci[B_PER], pb[B_PER], poh[B_PER], pow_[B_PER];
+    // B (gathered input) slots: pixel row kr of the chunk, column quad -> (tap, ci) decoded ONCE.  The slot's pixel of chunk c is
+    // p0 + kr + c CB: its (image, row, column) are recomputed per chunk from that index with two reciprocal multiplications + an exact
+    // fix-up -- straight-line VALU code that the scheduler places between the chunk's MFMAs.  (The first form advanced (b, oh, ow)
+    // incrementally with four wrap tests per slot and branched on the padding mode and the source side: a dozen exec-masked basic
+    // blocks per chunk that ran with the matrix pipe idle.)
+    int b_kr[B_PER], b_kh[B_PER], b_kw[B_PER], b_ci[B_PER];
     bool b_conv[B_PER], b_ones[B_PER], b_src0[B_PER];
 #pragma unroll
     for (int j = 0; j < B_PER; ++j) {
         const int idx = tid + j * NT;
         b_kr[j] = idx / (BN / 4);
         const int col = nn0 + (idx - b_kr[j] * (BN / 4)) * 4;
-        b_conv[j] = idx < B_CNT && col < Kconv;
-        b_ones[j] = idx < B_CNT && a.has_bias && col == Kconv;
+        b_conv[j] = col < Kconv;
+        b_ones[j] = a.has_bias && col == Kconv;
         const int tap = b_conv[j] ? col / a.Cin : 0;
         b_ci[j] = b_conv[j] ? col - tap * a.Cin : 0;
         b_src0[j] = b_ci[j] < a.C1;
-        b_kh[j] = tap / a.KW;
-        b_kw[j] = tap - b_kh[j] * a.KW;
-        const int64_t p = p0 + b_kr[j];
-        const int hw = a.Ho * a.Wo;
-        pb[j] = (int)(p / hw);
-        const int r = (int)(p - (int64_t)pb[j] * hw);
-        poh[j] = r / a.Wo;
-        pow_[j] = r - poh[j] * a.Wo;
+        b_kh[j] = tap / a.KW - a.pad;                        // tap offset relative to the strided output position
+        b_kw[j] = tap - (tap / a.KW) * a.KW - a.pad;
     }
-    f4v areg[A_PER], breg[B_PER];
+    const int hw = a.Ho * a.Wo;
+    const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)a.Wo;
+    const bool reflect = a.pad_mode == 1;
+    f4v areg[2][A_PER], breg[2][B_PER];                      // two staging sets: loads run two chunks ahead (see k_conv_gemm)
     int ld_chunk = 0;
-    auto load_chunk = [&]() {
-        const int left = npix - ld_chunk * CB;               // pixels of the slice that remain from this chunk on
-        const int soffz = (int)((p0 + (int64_t)ld_chunk * CB) * a.Cout * 4);
+    auto load_chunk = [&](int set) {
+        const int left = npix - ld_chunk * CB;               // pixels of the slice that remain from this chunk on (<= 0 past the end)
+        const int pc = p0 + ld_chunk * CB;
+        const int soffz = pc * a.Cout * 4;
 #pragma unroll
         for (int j = 0; j < A_PER; ++j)
-            areg[j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsz, (a_kr[j] < left) ? a_off[j] : OOB, soffz, 0));
+            areg[set][j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsz, (a_kr[j] < left) ? a_off[j] : OOB, soffz, 0));
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
-            int ys = poh[j] * a.stride + b_kh[j] - a.pad, xs = pow_[j] * a.stride + b_kw[j] - a.pad;
-            bool ok = b_conv[j] && b_kr[j] < left;
-            if (a.pad_mode == 1) { ys = reflect1(ys, a.Hs); xs = reflect1(xs, a.Ws); }
-            else ok = ok && ys >= 0 && ys < a.Hs && xs >= 0 && xs < a.Ws;
-            const unsigned o0 = (unsigned)(((pb[j] * Hl + (ys >> sh)) * Wl + (xs >> sh)) * a.C1 + b_ci[j]) * 4u;
-            const unsigned o1 = (unsigned)(((pb[j] * a.Hs + ys) * a.Ws + xs) * C2 + (b_ci[j] - a.C1)) * 4u;
-            f4v v;
-            if (src_mode == 0) {
-                v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? o0 : OOB, 0, 0));
-            } else if (src_mode == 1) {
-                v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs1, ok ? o1 : OOB, 0, 0));
-            } else {
-                v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs0, (ok && b_src0[j]) ? o0 : OOB, 0, 0));
-                const f4v v1 = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs1, (ok && !b_src0[j]) ? o1 : OOB, 0, 0));
+            const int p = pc + b_kr[j];
+            int b = (int)((float)p * inv_hw);                // floor(p / hw) up to +-1 ...
+            b -= (b * hw > p) ? 1 : 0;                       // ... made exact
+            b += ((b + 1) * hw <= p) ? 1 : 0;
+            const int r = p - b * hw;
+            int oh = (int)((float)r * inv_wo);
+            oh -= (oh * a.Wo > r) ? 1 : 0;
+            oh += ((oh + 1) * a.Wo <= r) ? 1 : 0;
+            const int ow = r - oh * a.Wo;
+            const int ys0 = oh * a.stride + b_kh[j], xs0 = ow * a.stride + b_kw[j];
+            const bool inside = ys0 >= 0 && ys0 < a.Hs && xs0 >= 0 && xs0 < a.Ws;
+            const int ys = reflect ? reflect1(ys0, a.Hs) : ys0, xs = reflect ? reflect1(xs0, a.Ws) : xs0;
+            const bool ok = b_conv[j] && b_kr[j] < left && (reflect || inside);
+            // (offset | out-of-range bit: written as `ok ? offset : OOB` the compiler sinks the offset arithmetic into an exec-masked branch)
+            const unsigned o0 = (unsigned)(((b * Hl + (ys >> sh)) * Wl + (xs >> sh)) * a.C1 + b_ci[j]) * 4u;
+            f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs0, o0 | ((ok && b_src0[j]) ? 0u : OOB), 0, 0));
+            if (TWO) {                                       // concat layer: the lanes of one load straddle the two sources
+                const unsigned o1 = (unsigned)(((b * a.Hs + ys) * a.Ws + xs) * C2 + (b_ci[j] - a.C1)) * 4u;
+                const f4v v1 = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs1, o1 | ((ok && !b_src0[j]) ? 0u : OOB), 0, 0));
                 v = b_src0[j] ? v : v1;
             }
-            if (b_ones[j]) v = (f4v){(b_kr[j] < left) ? 1.f : 0.f, 0.f, 0.f, 0.f};   // ones column: dW[:, Kconv] = sum_p dZ = bias gradient
-            breg[j] = v;
-            pow_[j] += CB;                                   // advance this slot's pixel by one chunk (CB <= 2 * Wo in this network;
-#pragma unroll
-            for (int w2 = 0; w2 < 4; ++w2)                   // four wraps cover Wo >= CB / 4)
-                if (pow_[j] >= a.Wo) { pow_[j] -= a.Wo; if (++poh[j] == a.Ho) { poh[j] = 0; ++pb[j]; } }
+            const f4v ones = {(b_kr[j] < left) ? 1.f : 0.f, 0.f, 0.f, 0.f};           // ones column: dW[:, Kconv] = sum_p dZ = bias gradient
+            breg[set][j] = b_ones[j] ? ones : v;
         }
         ++ld_chunk;
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, int set) {
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
             const int idx = tid + j * NT;
-            if (idx >= A_CNT) continue;
-            *(f4v*)&As[buf][a_kr[j]][(idx - a_kr[j] * (BM / 4)) * 4] = areg[j];
+            *(f4v*)&As[buf][a_kr[j]][(idx - a_kr[j] * (BM / 4)) * 4] = areg[set][j];
         }
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
             const int idx = tid + j * NT;
-            if (idx >= B_CNT) continue;
-            *(f4v*)&Bs[buf][b_kr[j]][(idx - b_kr[j] * (BN / 4)) * 4] = breg[j];
+            *(f4v*)&Bs[buf][b_kr[j]][(idx - b_kr[j] * (BN / 4)) * 4] = breg[set][j];
         }
     };
     f16v acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if (nchunks > 0) {
-        load_chunk();
-        store_chunk(0);
-    }
+    load_chunk(0);
+    load_chunk(1);
+    store_chunk(0, 0);
     __syncthreads();
     const int khalf = lane >> 5;
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) load_chunk();
-        float av[CB / 2], bv[CB / 2];                           // the chunk's fragments first, then the MFMAs (see k_conv_gemm)
+    auto chunk_step = [&](auto buf_c) {                      // loads / stores unconditional: one basic block per chunk (see k_conv_gemm)
+        constexpr int buf = decltype(buf_c)::value;
+        load_chunk(buf);
+        float av[CB / 2], bv[CB / 2];
 #pragma unroll
         for (int kk = 0; kk < CB / 2; ++kk) {
             av[kk] = As[buf][kk * 2 + khalf][wm * 32 + (lane & 31)];
@@ -1274,8 +1388,12 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
         for (int kk = 0; kk < CB / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, CB / 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, CB / 2, 0);
-        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        store_chunk(buf ^ 1, buf ^ 1);
         __syncthreads();
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk_step(std::integral_constant<int, 0>{});
+        if (c + 1 < nchunks) chunk_step(std::integral_constant<int, 1>{});
     }
     float* slab = a.slabs + (int64_t)bz * a.Mpad * a.Npad;
     const int n = nn0 + wn * 32 + (lane & 31);
@@ -2031,6 +2149,11 @@ static int tile_waves(int bm, int bn) {
 static GemmCfg choose_cfg(int64_t rows, int cols, int K, int cb, bool allow_split, GemmCfg force = GemmCfg{0, 0, 0}) {
     if (force.bm) { GemmCfg f = force; if (!allow_split && f.S > 1) f.S = 1; if (f.bm == 128 && f.bn == 128 && cb != 16) f.bn = 64; return f; }
     GemmCfg c = {64, 64, 1};
+    // round 3 (branch-free loaders, profiles/r03_gemm_tune_final.txt): with >= 128 columns the 32 x 128 tile (four waves side by side on ONE
+    // 32-row A block) wins 5-10 % over 64 x 64 at the same slice count -- the gathered A operand is the expensive one to stage, and this
+    // shape stages half as much of it per MFMA (layer3 41.1 -> 37.3 us, layer4 41.0 -> 37.3, up(3,1) 67.4 -> 62.9, up(2,1) backward-data
+    // 61.5 -> 56.8 = 99.7 TF/s)
+    if (cols >= 128) { c.bm = 32; c.bn = 128; }
     if (cols <= 32) {
         c.bm = 128; c.bn = 32;
         if (((rows + 127) / 128) * ((cols + 31) / 32) < 600) c.bm = 64;
@@ -2217,8 +2340,9 @@ static int conv_fwd_impl(const float* src0, const float* src1, int C1, int up, c
     E2E_REQUIRE(Hs % up == 0 && Ws % up == 0 && ld_fwd % 4 == 0 && ld_fwd >= Cout, E2E_ERR_ARG, "e2e_conv2d_fwd: bad sizes");
     const int vec = (Cin % 16 == 0 && (C1 == Cin || C1 % 16 == 0)) ? 4 : 1;
     E2E_REQUIRE(vec == 4 || (C1 == Cin && up == 1), E2E_ERR_ARG, "e2e_conv2d_fwd: the scalar path (Cin %% 16 != 0) takes a single full-resolution source");
-    E2E_REQUIRE((int64_t)B * Hs * Ws * Cin * 4 < (1ll << 31) && (int64_t)KH * KW * Cin * ld_fwd * 4 < (1ll << 31), E2E_ERR_ARG,
-                "e2e_conv2d_fwd: operands must stay below 2 GB (32-bit buffer offsets)");
+    E2E_REQUIRE((int64_t)B * Hs * Ws * Cin * 4 < (1ll << 30) && (int64_t)KH * KW * Cin * ld_fwd * 4 < (1ll << 31), E2E_ERR_ARG,
+                "e2e_conv2d_fwd: activations must stay below 1 GB, weights below 2 GB (32-bit buffer offsets with out-of-range markers)");
+    E2E_REQUIRE(vec != 4 || (KH <= 3 && KW <= 3), E2E_ERR_ARG, "e2e_conv2d_fwd: the channel-quad loader takes kernels up to 3 x 3");
     ConvArgs a{};
     a.src0 = src0; a.src1 = src1; a.w = w_fwd; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
     a.B = B; a.Hs = Hs; a.Ws = Ws; a.Cin = Cin; a.C1 = C1; a.up = up;
@@ -2278,8 +2402,8 @@ static int bwd_data_impl(const float* dz, const float* w_bwd, int ld_bwd, float*
                 "e2e_conv2d_bwd_data: the fused input-activation derivative takes ReLU / ELU, the activation's output and a zero-padded layer");
     E2E_REQUIRE(dz && w_bwd && dxp && B > 0 && Cin > 0 && Cout > 0 && Cout % 16 == 0, E2E_ERR_ARG, "e2e_conv2d_bwd_data: bad argument (Cout %% 16 == 0)");
     E2E_REQUIRE(ld_bwd % 4 == 0 && ld_bwd >= Cin && (stride == 1 || stride == 2), E2E_ERR_ARG, "e2e_conv2d_bwd_data: bad sizes");
-    E2E_REQUIRE((int64_t)B * Ho * Wo * Cout * 4 < (1ll << 31) && (int64_t)KH * KW * Cout * ld_bwd * 4 < (1ll << 31), E2E_ERR_ARG,
-                "e2e_conv2d_bwd_data: operands must stay below 2 GB (32-bit buffer offsets)");
+    E2E_REQUIRE((int64_t)B * Ho * Wo * Cout * 4 < (1ll << 30) && (int64_t)KH * KW * Cout * ld_bwd * 4 < (1ll << 31) && KH <= 3 && KW <= 3, E2E_ERR_ARG,
+                "e2e_conv2d_bwd_data: gradients must stay below 1 GB, weights below 2 GB (32-bit buffer offsets), kernels up to 3 x 3");
     // 16 -> 16 channels on the padded grid of a reflection-padded layer (upconv(0,1)): dXp[q] = sum_t dZ[q - t] Wb[t], patch kernel
     if (!force.bm && KH == 3 && KW == 3 && stride == 1 && pad == 1 && pad_mode == 1 && Cin == 16 && Cout == 16 && !accumulate && !in_act && !pre_add && ld_bwd >= 16) {
         ThinArgs t{dz, w_bwd, nullptr, dxp, B, Ho, Wo, Hs + 2, Ws + 2, ld_bwd, ACT_NONE, 2, 1};
@@ -2481,7 +2605,7 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
     a.Ngemm = KH * KW * Cin + a.has_bias;
     const int64_t P = (int64_t)B * Ho * Wo;
     // lean VEC-4 kernel: 32 pixels per chunk; needs Cout % 4 == 0, 32-bit offsets and image rows of at least 8 pixels
-    const bool lean = vec == 4 && Cout % 4 == 0 && Wo >= 8 && (int64_t)B * Hs * Ws * Cin * 4 < (1ll << 31) && P * Cout * 4 < (1ll << 31);
+    const bool lean = vec == 4 && Cout % 4 == 0 && Wo >= 8 && (int64_t)B * Hs * Ws * Cin * 4 < (1ll << 31) && P * Cout * 4 < (1ll << 31) && P < (1ll << 24);
     hipStream_t st = (hipStream_t)stream;
     // the RGB stem: patch kernel + the common slab reduction
     if (KH == 7 && KW == 7 && stride == 2 && pad == 3 && pad_mode == 0 && Cin == 3 && Cout == 64 && C1 == Cin && up == 1 && !dbias &&
@@ -2521,8 +2645,13 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
     if (use16) {
         hipLaunchKernelGGL((k_wgrad_gemm16<10, 32>), g, dim3(256), 0, st, a);
     } else if (lean) {
-        if (tm == 32) hipLaunchKernelGGL((k_wgrad_gemm4<1, 4, 32>), g, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_wgrad_gemm4<2, 2, 32>), g, dim3(256), 0, st, a);
+        if (tm == 32) {
+            if (src1) hipLaunchKernelGGL((k_wgrad_gemm4<1, 4, 32, true>), g, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_wgrad_gemm4<1, 4, 32, false>), g, dim3(256), 0, st, a);
+        } else {
+            if (src1) hipLaunchKernelGGL((k_wgrad_gemm4<2, 2, 32, true>), g, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_wgrad_gemm4<2, 2, 32, false>), g, dim3(256), 0, st, a);
+        }
     } else if (tm == 32) {
         if (vec == 4) hipLaunchKernelGGL((k_wgrad_gemm<1, 4, 4>), g, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_wgrad_gemm<1, 4, 1>), g, dim3(256), 0, st, a);
