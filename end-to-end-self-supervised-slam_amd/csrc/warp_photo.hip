@@ -170,11 +170,19 @@ __global__ void k_grid_sample_bwd(const float* __restrict__ in, e2e_strides s, c
             giy += g * ((sw - nw) * (1.f - bl.tx) + (se - ne) * bl.tx);
             if (gin_fx) {  // scatter-add into a (B,C,Hi,Wi) image of 2^-48 fixed-point sums: integer adds commute, so the result does
                 // not depend on the arrival order (bitwise reproducible; |sum| < 32768, resolution 3.6e-15)
+                // A contribution that is not finite, or too large for the format (|v| >= 4096: sums are specified below 32768), is NOT added:
+                // it raises the poison word behind the image (gin_fx[B C Hi Wi]) and the conversion pass then returns NaN everywhere --
+                // torch would put NaN / Inf at the affected pixels; a silently wrapped or saturated finite value is the one wrong answer
                 unsigned long long* gi = gin_fx + (((int64_t)b * C + c) * Hi + bl.y0) * Wi + bl.x0;
-                if (bl.in_y0 & bl.in_x0) atomicAdd(gi, (unsigned long long)__double2ll_rn((double)(g * bl.wnw) * 281474976710656.0));
-                if (bl.in_y0 & bl.in_x1) atomicAdd(gi + 1, (unsigned long long)__double2ll_rn((double)(g * bl.wne) * 281474976710656.0));
-                if (bl.in_y1 & bl.in_x0) atomicAdd(gi + Wi, (unsigned long long)__double2ll_rn((double)(g * bl.wsw) * 281474976710656.0));
-                if (bl.in_y1 & bl.in_x1) atomicAdd(gi + Wi + 1, (unsigned long long)__double2ll_rn((double)(g * bl.wse) * 281474976710656.0));
+                const float v4[4] = {g * bl.wnw, g * bl.wne, g * bl.wsw, g * bl.wse};
+                const bool on4[4] = {(bool)(bl.in_y0 & bl.in_x0), (bool)(bl.in_y0 & bl.in_x1), (bool)(bl.in_y1 & bl.in_x0), (bool)(bl.in_y1 & bl.in_x1)};
+                const int64_t of4[4] = {0, 1, Wi, (int64_t)Wi + 1};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!on4[q]) continue;
+                    if (fabsf(v4[q]) < 4096.f) atomicAdd(gi + of4[q], (unsigned long long)__double2ll_rn((double)v4[q] * 281474976710656.0));
+                    else atomicOr(gin_fx + (int64_t)gridDim.y * C * Hi * Wi, 1ull);
+                }
             } else if (gin) {  // floating-point scatter-add: run-to-run differences in the last bits (kept for callers without scratch)
                 float* gi = gin + (((int64_t)b * C + c) * Hi + bl.y0) * Wi + bl.x0;
                 if (bl.in_y0 & bl.in_x0) atomicAdd(gi, g * bl.wnw);
@@ -701,8 +709,9 @@ int e2e_grid_sample_bwd(const float* input, e2e_strides in_strides, const float*
 }
 
 __global__ void k_fixed48_to_float(const long long* __restrict__ fx, float* __restrict__ out, int64_t n) {
+    const bool poisoned = fx[n] != 0;                     // a non-finite / out-of-range contribution was refused: the result is not a number
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = (float)((double)fx[i] * (1.0 / 281474976710656.0));
+        out[i] = poisoned ? __uint_as_float(0x7FC00000u) : (float)((double)fx[i] * (1.0 / 281474976710656.0));
 }
 
 int e2e_grid_sample_bwd_exact(const float* input, e2e_strides in_strides, const float* grid, const float* g_out, float* g_grid,
@@ -713,7 +722,8 @@ int e2e_grid_sample_bwd_exact(const float* input, e2e_strides in_strides, const 
     E2E_REQUIRE(padding_mode == E2E_PADDING_BORDER || padding_mode == E2E_PADDING_ZEROS, E2E_ERR_ARG,
                 "e2e_grid_sample_bwd_exact: padding_mode %d not supported (zeros|border)", padding_mode);
     const int64_t n = (int64_t)B * C * Hi * Wi;
-    (void)hipMemsetAsync(g_input_fixed, 0, (size_t)n * sizeof(long long), (hipStream_t)stream);
+    E2E_REQUIRE(hipMemsetAsync(g_input_fixed, 0, (size_t)(n + 1) * sizeof(long long), (hipStream_t)stream) == hipSuccess, E2E_ERR_LAUNCH,
+                "e2e_grid_sample_bwd_exact: hipMemsetAsync of the fixed-point scratch failed");
     DISPATCH_PAD_ALIGN(k_grid_sample_bwd, flat_grid(B, (int64_t)Ho * Wo), dim3(256), 0, (hipStream_t)stream, input,
                        in_strides, grid, g_out, g_grid, g_input, C, Hi, Wi, Ho, Wo, (unsigned long long*)g_input_fixed);
     hipLaunchKernelGGL(k_fixed48_to_float, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

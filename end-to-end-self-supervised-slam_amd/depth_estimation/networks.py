@@ -30,11 +30,19 @@ class _ConvBN(nn.Module):
         """relu?( BN(conv(x)) + residual? ).  A frozen BatchNorm (the refinement mode freezes every parameter whose name
         contains "bn", online_adaption.py:182-184) is folded into the convolution's epilogue as constants; one whose
         affine still trains (the `downsample.1` ones) runs e2ehip's affine kernel behind the convolution so that gamma / beta
-        receive their gradients.  Batch-statistics (train-mode) BatchNorm is not on the refinement path: the reference
-        switches every module to eval() before refining (online_adaption.py:175-184, train_depth.py:198-207)."""
+        receive their gradients.
+
+        Train-mode BatchNorm (batch statistics + running-average update): the reference only switches to eval() when
+        MODEL.refinement_mode is set (online_adaption.py:175-184, train_depth.py:246-247); with the flag off the network stays in train
+        mode.  That configuration is NOT the benchmarked path and has no native kernel: the convolution runs on the HIP kernel
+        and the normalisation itself goes through torch.nn.functional.batch_norm -- the one place where an ATen operator computes
+        on behalf of the network ("train-mode BatchNorm")."""
         if bn.training:
-            raise NotImplementedError("train-mode BatchNorm (batch statistics) is not on the refinement path: call .eval() "
-                                      "(set_refinement_mode / set_eval) as the reference does before refining")
+            y = nn_ops.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0], "zeros", None, None, in_norm=in_norm)
+            y = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
+            if residual is not None:
+                y = y + residual
+            return torch.relu(y) if relu else y
         return nn_ops.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0], "zeros", "relu" if relu else None, _bn_args(bn),
                              residual=residual, in_norm=in_norm)
 

@@ -150,6 +150,16 @@ class FusionMap:
         self._knn_dirty = True
 
 
+def _mark_updated_on_device(self, index_current):
+    """Bookkeeping after a captured map update was REPLAYED (the Python side of step_resident / knn_index did not run)."""
+    self._M = None
+    self._assoc_M = None
+    self._knn_dirty = not index_current
+
+
+FusionMap.mark_updated_on_device = _mark_updated_on_device
+
+
 class ResidentKnnIndex:
     """Exact 1-NN grid over the live rows of a FusionMap, in ONE buffer sized for the map's capacity."""
     resident = True

@@ -113,7 +113,7 @@ class _GridSample(torch.autograd.Function):
         gg = torch.empty_like(grid)
         if ctx.needs_input_grad[0]:      # gradient wrt the sampled image: a scatter -- fixed-point integer accumulation, bitwise reproducible
             gi = torch.empty(B, C, Hi, Wi, device=g.device, dtype=torch.float32)
-            fx = torch.empty(B, C, Hi, Wi, device=g.device, dtype=torch.int64)
+            fx = torch.empty(B * C * Hi * Wi + 1, device=g.device, dtype=torch.int64)      # + the poison word (non-finite / out-of-range contributions)
             L.call("e2e_grid_sample_bwd_exact", L.ptr(inp), L.strides4(inp), L.ptr(grid), L.ptr(g), L.ptr(gg), L.ptr(fx), L.ptr(gi),
                    B, C, Hi, Wi, Ho, Wo, pad, align, L.stream())
             return gi, gg, None, None

@@ -40,7 +40,7 @@ class RefineStepPlan:
         # ---- resident tensors of a step (pair order: index 0 = previous keyframe / source, 1 = new keyframe / target) ----
         self.colors = self.net.x.t                                  # (2,H,W,3) NHWC, the network's input buffer
         self.gt = torch.zeros(2, H, W, 1, **f)
-        self.K, self.inv_K, self.T, self.pose_tgt = (torch.eye(4, **f).reshape(1, 4, 4).clone() for _ in range(4))
+        self.K, self.inv_K, self.T, self.pose_tgt, self.pose_src = (torch.eye(4, **f).reshape(1, 4, 4).clone() for _ in range(5))
         self.median_gt = torch.zeros(1, **f)
         self.ws_med = torch.empty(lib.e2e_median_workspace_bytes(), device=self.dev, dtype=torch.uint8)
         self.delta, self.depth, self.init = (torch.empty(2, 1, H, W, **f) for _ in range(3))
@@ -69,7 +69,7 @@ class RefineStepPlan:
         self.net.refresh_layouts()
 
     # ---- per keyframe -----------------------------------------------------------------------------------------------------
-    def set_pair(self, colors_prev, colors_cur, gt_prev, gt_cur, K, T_host, pose_tgt, inv_K=None):
+    def set_pair(self, colors_prev, colors_cur, gt_prev, gt_cur, K, T_host, pose_tgt, inv_K=None, pose_src=None):
         """Load a keyframe pair into the resident buffers: frames (H,W,3) in [0,1], ground-truth depths (H,W,1), intrinsics K
         (4,4), relative transform T (4,4) = pinv(P_prev) P_cur and the target pose (4,4).  All copies, no kernels of ours but the
         median of the ground-truth depths (online_adaption.py:295: torch.median(gt_depths))."""
@@ -81,6 +81,8 @@ class RefineStepPlan:
         self.inv_K[0].copy_(torch.pinverse(K) if inv_K is None else inv_K)      # callers with constant intrinsics pass the inverse
         self.T[0].copy_(T_host, non_blocking=True)
         self.pose_tgt[0].copy_(pose_tgt)
+        if pose_src is not None:
+            self.pose_src[0].copy_(pose_src)
         L.call("e2e_median_lower", L.ptr(self.gt), self.gt.numel(), L.ptr(self.median_gt), L.ptr(self.ws_med), L.stream())
 
     # ---- graph plumbing ---------------------------------------------------------------------------------------------------
@@ -190,6 +192,20 @@ class RefineStepPlan:
         online_adaption.py:329-344) -> (2,1,H,W) resident buffer."""
         self._run("fwd", self._forward)
         return self.depth
+
+    def update_map(self, fmap, first):
+        """The keyframe's PointFusion map step(s) (online_adaption.py:347-363 with the ground-truth poses) and the rebuild of the
+        nearest-neighbour index over the grown map, from the RESIDENT buffers of the loaded pair -- frames, median-scaled depths of the
+        last forward (predict_depths), intrinsics, the two poses -- so that every launch argument is constant and the ~25 launches
+        replay as one captured graph (issued eagerly they left the GPU idle ~8 us per launch: the host cannot run ahead of a replaying
+        graph).  first: the map is empty, the previous keyframe's frame is fused before the new one's."""
+        def fn():
+            if first:
+                fmap.step_resident(self.colors[0], self.depth[0, 0], self.K[0], self.pose_src[0])
+            fmap.step_resident(self.colors[1], self.depth[1, 0], self.K[0], self.pose_tgt[0])
+            fmap.knn_index(self.N)                                  # rebuilt in place from the device-resident point count
+        self._run(("map", bool(first), id(fmap)), fn)
+        fmap.mark_updated_on_device(index_current=True)
 
     def losses(self):
         """(photometric mean, regulariser sum of means, 3-D loss mean) of the last step as device tensors (no sync)."""

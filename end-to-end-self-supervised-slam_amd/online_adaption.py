@@ -242,7 +242,7 @@ class SLAM:
         if T is None:
             T = self._T_dev[(prev, cur)] = torch_poses_to_transforms(self._poses_h[:, [prev, cur]])[0, 1].to(self.device)
         sp.set_pair(self.colors[0, prev], self.colors[0, cur], self.gt_depths[0, prev], self.gt_depths[0, cur], self.intrinsics[0, 0], T, self.poses[0, cur],
-                    inv_K=self._inv_K)
+                    inv_K=self._inv_K, pose_src=self.poses[0, prev])
 
     def refinement(self, prev, cur, max_steps=None, next_pair=None):
         """One keyframe: `OPTIMIZATION.refinement_steps` optimisation steps on the pair (prev, cur), then the map update
@@ -274,6 +274,14 @@ class SLAM:
                 self._log_step(rec, refine_step, nsteps)
         # map update (online_adaption.py:329-366): one more forward with the refined network, then PointFusion
         depth = sp.predict_depths()
+        if a.MODEL.odom == "gt":
+            # everything the map step reads sits in the plan's resident buffers (frames, scaled depths, intrinsics, both poses): one
+            # captured graph incl. the rebuild of the nearest-neighbour index; the next pair's inputs are loaded AFTER it
+            sp.update_map(self.map, self.first_iter)
+            if next_pair is not None:
+                self._load_pair(sp, *next_pair)
+                self._preloaded = tuple(next_pair)
+            return
         if next_pair is not None:                   # stream-ordered behind the forward above; the map update reads neither of these buffers
             self._load_pair(sp, *next_pair)
             self._preloaded = tuple(next_pair)

@@ -76,8 +76,10 @@ int e2e_grid_sample_bwd(const float* input, e2e_strides in_strides, const float*
                         const float* g_out, float* g_grid, float* g_input, int B, int C, int Hi,
                         int Wi, int Ho, int Wo, int padding_mode, int align_corners, void* stream);
 /* The same with a BITWISE REPRODUCIBLE gradient with respect to the sampled image: the bilinear adjoint is a data-dependent scatter; its
- * contributions are accumulated as 2^-48 fixed-point integers (integer adds commute: no dependence on arrival order; |sum| < 32768,
- * resolution 3.6e-15) in g_input_fixed (B*C*Hi*Wi int64 of scratch, zeroed here) and converted to g_input (B,C,Hi,Wi) afterwards. */
+ * contributions are accumulated as 2^-48 fixed-point integers (integer adds commute: no dependence on arrival order; resolution 3.6e-15)
+ * in g_input_fixed (B*C*Hi*Wi + 1 int64 of scratch, zeroed here) and converted to g_input (B,C,Hi,Wi) afterwards.  Range: every
+ * contribution |g_out * weight| < 4096 and every sum < 32768; a contribution that is not finite or not below 4096 is refused and raises
+ * the scratch's last word, and g_input then comes back as NaN everywhere (never a wrapped or saturated finite value). */
 int e2e_grid_sample_bwd_exact(const float* input, e2e_strides in_strides, const float* grid, const float* g_out,
                               float* g_grid, long long* g_input_fixed, float* g_input, int B, int C, int Hi, int Wi,
                               int Ho, int Wo, int padding_mode, int align_corners, void* stream);

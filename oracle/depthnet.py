@@ -129,7 +129,13 @@ def random_state_dict(seed=0, bn_noise=True):
 
 
 # ---- functional forward ---------------------------------------------------------------------
+BN_TRAINING = [False]     # True: batch statistics + running-average update (nn.BatchNorm2d in train mode, momentum 0.1) -- the
+                          # configuration MODEL.refinement_mode = False leaves the reference in (train_depth.py:246-247)
+
+
 def _bn_eval(x, sd, p):
+    if BN_TRAINING[0]:
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], True, 0.1, 1e-5)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
                         sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
 

@@ -102,3 +102,34 @@ def test_full_size_pair_forward_backward_vs_oracle():
         a, b = plan.sink(params[k]).cpu(), sd_o[k].grad
         err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
         assert err < GRAD_TOL, (k, err)
+
+
+def test_train_mode_batchnorm_compatibility_path():
+    """MODEL.refinement_mode = False leaves the network in train mode (train_depth.py:246-247): BatchNorm then normalises with BATCH
+    statistics and updates its running averages.  Not the benchmarked path -- convolutions on the HIP kernels, the normalisation through
+    torch.nn.functional.batch_norm -- but it has to run and agree with the oracle's train-mode evaluation (forward, gradients, buffers)."""
+    from depth_estimation.networks import DispResNet_Indoor
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(2, 64, 96, 3, generator=g)
+    wgt = torch.randn(2, 1, 64, 96, generator=g) / (64 * 96)
+    sd = depthnet.random_state_dict(0)
+    m = DispResNet_Indoor(18, False)
+    m.load_state_dict(sd)
+    m.to(DEV).train()
+    disp = m(x.to(DEV), 0)[("disp", 0, 0)]
+    (disp * wgt.to(DEV)).sum().backward()
+    # oracle: the functional restatement with BatchNorm in training mode
+    keys = [k for k in sd if sd[k].dtype.is_floating_point and "running" not in k]
+    sd_o = {k: (v.clone().requires_grad_(True) if k in keys else v.clone()) for k, v in sd.items()}
+    depthnet.BN_TRAINING[0] = True
+    try:
+        d_ref = depthnet.disp_forward(sd_o, x)
+        (d_ref * wgt).sum().backward()
+    finally:
+        depthnet.BN_TRAINING[0] = False
+    torch.testing.assert_close(disp.detach().cpu(), d_ref.detach(), rtol=1e-4, atol=1e-5)
+    pm = dict(m.named_parameters())
+    for k in ("encoder.encoder.conv1.weight", "encoder.encoder.bn1.weight", "encoder.encoder.layer2.0.downsample.1.bias", "decoder.decoder.0.conv.conv.weight"):
+        a, b = pm[k].grad.cpu(), sd_o[k].grad
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9, k
+    torch.testing.assert_close(dict(m.named_buffers())["encoder.encoder.bn1.running_mean"].cpu(), sd_o["encoder.encoder.bn1.running_mean"], rtol=1e-4, atol=1e-6)

@@ -194,7 +194,7 @@ def test_knn_full_frame_properties():
     assert torch.equal(d[:2000].cpu(), dr) and torch.equal(i[:2000].cpu(), ir)
 
 
-@pytest.mark.parametrize("case", ["surface", "clustered", "far_queries", "degenerate", "big_map", "sparse_far", "large_coordinates"])
+@pytest.mark.parametrize("case", ["surface", "clustered", "far_queries", "degenerate", "big_map", "sparse_far", "large_coordinates", "dense_5m_map"])
 def test_knn_grid_equals_brute(case):
     """The grid search must return exactly what the brute force returns (distances AND indices, ties included) on
     surface-like data, heavy clusters with duplicates, queries far outside the reference set, and a degenerate cloud."""
@@ -222,6 +222,18 @@ def test_knn_grid_equals_brute(case):
         near = torch.stack([v[:, 0], 1.2 * torch.cos(v[:, 1]) + 0.01, v[:, 1]], 1)
         far = torch.rand(10000, 3, generator=g) * torch.tensor([20.0, 6.0, 20.0]) - torch.tensor([10.0, 3.0, 10.0])
         q = torch.cat([near, far, ref[11:12], ref[5100:5101]], 0)
+    elif case == "dense_5m_map":   # a late-sequence map: 5.2 M points = 13 overlapping passes over the same 5 x 3 m surface (hundreds of points per
+        n, layers = 400_000, 13    # 2 cm cell), 60 % of the queries a few millimetres off the surface, the rest looking at unmapped space
+        refs = []
+        for _ in range(layers):
+            u = torch.rand(n, 2, generator=g) * torch.tensor([5.0, 3.0]) - torch.tensor([2.5, 1.5])
+            refs.append(torch.stack([u[:, 0], u[:, 1], 2.0 + 0.4 * torch.sin(u[:, 0] * 1.3) * torch.cos(u[:, 1]) + 0.002 * torch.randn(n, generator=g)], 1))
+        ref = torch.cat(refs, 0)
+        ref[70000:70200] = ref[5]
+        v = torch.rand(12000, 2, generator=g) * torch.tensor([5.0, 3.0]) - torch.tensor([2.5, 1.5])
+        near = torch.stack([v[:, 0], v[:, 1], 2.0 + 0.4 * torch.sin(v[:, 0] * 1.3) * torch.cos(v[:, 1]) + 0.004], 1)
+        far = torch.rand(8000, 3, generator=g) * torch.tensor([9.0, 6.0, 5.0]) - torch.tensor([4.5, 3.0, 0.5])
+        q = torch.cat([near, far, ref[5:6]], 0)
     elif case == "large_coordinates":   # a dense sheet 300 m from the origin: fp32 ulp there is 3e-5 m, several times the cell-face
         n = 200000                          # slack a fixed 1e-5 m margin would give; queries both near the sheet and 2 km away
         u = torch.rand(n, 2, generator=g) * 6

@@ -354,3 +354,24 @@ def test_grid_sample_input_gradient_matches_torch_and_is_bitwise_reproducible(pa
     torch.testing.assert_close(runs[0][0].cpu(), ir.grad, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(runs[0][1].cpu(), gr.grad, rtol=1e-4, atol=1e-4)
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+
+
+def test_grid_sample_input_gradient_refuses_non_finite_and_huge_contributions():
+    """The fixed-point accumulation of e2e_grid_sample_bwd_exact holds sums below 32768 with contributions below 4096: an upstream
+    gradient that is NaN / Inf or far out of range must not come back as a finite, plausible number (a wrapped 64-bit integer) -- the
+    whole image gradient is NaN then, loudly."""
+    from e2ehip import ops
+    g = torch.Generator().manual_seed(9)
+    B, C, H, W = 1, 2, 24, 32
+    img = torch.randn(B, C, H, W, generator=g)
+    grid = torch.rand(B, H, W, 2, generator=g) * 1.6 - 0.8
+    for bad in (float("nan"), float("inf"), 1.0e7):
+        gout = torch.randn(B, C, H, W, generator=g)
+        gout[0, 1, 5, 7] = bad
+        idv, gdv = img.to(DEV).requires_grad_(True), grid.to(DEV).requires_grad_(True)
+        ops.grid_sample(idv, gdv, padding_mode="border", align_corners=False).backward(gout.to(DEV))
+        assert torch.isnan(idv.grad).all(), bad
+    gout = torch.randn(B, C, H, W, generator=g) * 100.0                        # large but legal: unaffected
+    idv, gdv = img.to(DEV).requires_grad_(True), grid.to(DEV).requires_grad_(True)
+    ops.grid_sample(idv, gdv, padding_mode="border", align_corners=False).backward(gout.to(DEV))
+    assert torch.isfinite(idv.grad).all()

@@ -1,0 +1,35 @@
+#!/bin/bash
+# usage: tools/evidence.sh <tag>  -- the measured evidence of a round, under gpurun_out/evidence_<tag>/ (copy what is to be judged to profiles/):
+#   bench_default.json          python3 bench.py --gpus 1 --steps 20 --warmup 5                      (the driver's command)
+#   bench_fullpass.json         ... --steps 177 --warmup 6: one whole pass of the 60-frame sequence (59 keyframes x 3 steps)
+#   bench_gradicp.json          ... --odom gradicp: frame-to-model GradICP odometry in the map step, reports the ATE
+#   bench_overlap.json          E2E_WGRAD_OVERLAP=1: backward-weight chains on a second stream (A/B of the one-stream default)
+#   kernel_stats.txt, timeline.txt   rocprofv3 --kernel-trace --stats of `bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-roofline`
+#   pmc_traffic.{txt,json}      tools/bench_pmc.sh (FETCH_SIZE / WRITE_SIZE passes, stamped with the source hash)
+#   gemm_tune.txt               tools/gemm_tune.py both
+export TMPDIR=/tmp
+TAG=$1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/evidence_$TAG; mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default $?" > $OUT/progress.txt
+python3 bench.py --gpus 1 --steps 177 --warmup 6 --no-cpu-baseline > $OUT/bench_fullpass.json 2> $OUT/bench_fullpass.err; echo "fullpass $?" >> $OUT/progress.txt
+E2E_WGRAD_OVERLAP=1 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/bench_overlap.json 2> $OUT/bench_overlap.err; echo "overlap $?" >> $OUT/progress.txt
+timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --odom gradicp > $OUT/bench_gradicp.json 2> $OUT/bench_gradicp.err; echo "gradicp $?" >> $OUT/progress.txt
+rocprofv3 --kernel-trace --stats -d /tmp/ev_$TAG -o full --output-format csv -- python3 bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+echo "rocprof $?" >> $OUT/progress.txt
+f=$(find /tmp/ev_$TAG -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/kernel_stats.csv
+t=$(find /tmp/ev_$TAG -name "*kernel_trace.csv" | head -1)
+python3 tools/trace_timeline.py "$t" 0.45 k_pf_append 40 > $OUT/timeline.txt 2>&1
+python3 - "$f" > $OUT/kernel_stats.txt <<'PY'
+import csv,sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+tot=sum(float(r['TotalDurationNs']) for r in rows)
+print(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu-baseline --no-roofline ; total kernel time {tot/1e6:.1f} ms")
+for r in rows[:70]:
+    print(f"{r['Name'][:90]:90s} calls {r['Calls']:>6s} avg_us {float(r['AverageNs'])/1e3:9.1f} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} {100*float(r['TotalDurationNs'])/tot:5.1f}%")
+PY
+bash tools/bench_pmc.sh $TAG > $OUT/pmc.log 2>&1
+cp gpurun_out/benchpmc_$TAG/traffic.txt $OUT/pmc_traffic.txt; cp gpurun_out/benchpmc_$TAG/traffic.json $OUT/pmc_traffic.json
+echo "pmc done" >> $OUT/progress.txt
+timeout -k 10 500 python3 tools/gemm_tune.py both > $OUT/gemm_tune.txt 2>&1; echo "tune $?" >> $OUT/progress.txt
+cat $OUT/progress.txt; head -c 300 $OUT/bench_default.json; echo; head -c 300 $OUT/bench_fullpass.json; echo; head -c 300 $OUT/bench_gradicp.json
