@@ -96,7 +96,6 @@ __global__ __launch_bounds__(KT) void k_knn1_bwd(const float* __restrict__ g, co
 static inline int grid_max_for(int64_t n2) { return n2 >= GRID_BIG_N2 ? GRID_MAX_BIG : GRID_MAX_SMALL; }
 static inline int64_t grid_cells_cap(int64_t n2) { const int64_t g = grid_max_for(n2); return g * g * g; }
 #define GRID_HMIN 0.01f
-#define GRID_AXIS_MAX 1024    // most cells along one axis (the total stays within the gmax^3 budget the index was allocated for)
 #define GRID_RMAX 3      // shells of the one-query-per-lane pass; whatever it cannot bound goes to the wave-per-query pass
                          // (2: 130 + 158 us, 3: 180 + 52 us, 4: 282 + 45 us on the 256^3 grid)
 #define SCAN_BLOCK 1024
@@ -187,21 +186,13 @@ __global__ __launch_bounds__(BBOX_BLOCKS) void k_grid_setup(GridInfo* gi, const 
         lo[c] = fkey_inv(gi->bb[c]);
         ext = fmaxf(ext, fkey_inv(gi->bb[3 + c]) - lo[c]);
     }
-    // Cell size.  Round 2: cubic budget, h = longest extent / (gmax - 1) -- a map is a thin SURFACE inside a box that is rarely a cube, so
-    // most of the gmax^3 cells the index has room for were never addressed while the occupied ones held hundreds of points late in a
-    // sequence (the query cost grew 2.5x over 59 keyframes).  Now the cells are as small as the cell BUDGET (gmax^3 cells of storage,
-    // unchanged) allows for the box at hand: h = cbrt(volume / budget), at most GRID_AXIS_MAX cells along an axis, never below
-    // GRID_HMIN; the build touches the same arrays as before, a query scans ~(h_new / h_old)^2 of the points it used to.
-    float ex[3];
-    for (int c = 0; c < 3; ++c) ex[c] = fmaxf(fkey_inv(gi->bb[3 + c]) - lo[c], 0.f);
-    const float budget = 0.9f * (float)gmax * (float)gmax * (float)gmax;
-    float h = fmaxf(ext / (float)(GRID_AXIS_MAX - 1), GRID_HMIN);
-    for (int it = 0; it < 64; ++it) {                     // grow h until the box fits the budget (a handful of 6 % steps at most)
-        const float cells = (floorf(ex[0] / h) + 1.f) * (floorf(ex[1] / h) + 1.f) * (floorf(ex[2] / h) + 1.f);
-        if (cells <= budget) break;
-        h *= fmaxf(cbrtf(cells / budget), 1.02f);
-    }
-    gmax = GRID_AXIS_MAX;
+    // Cell size: cubic budget, h = longest extent / (gmax - 1).  A map is a thin surface in a box that is rarely a cube, so many of the
+    // gmax^3 cells are never addressed; round 3 tried cells as small as the cell budget allows for the box at hand (h = cbrt(volume /
+    // budget), up to 1024 cells along an axis).  Exact all the same, but SLOWER on the refinement path: the queries are back-projected
+    // PREDICTED depths, typically several cells away from the map surface, and the shell search visits ~(1/h)^3 cells to cover that
+    // distance -- 0.71 -> 1.12 ms per keyframe at 1.66 M points, 177.3 -> 172.0 steps/s over a whole pass
+    // (profiles/r03_knn_adaptive_cells_rejected.txt).  Reverted.
+    const float h = fmaxf(ext / (float)(gmax - 1), GRID_HMIN);
     float maxabs = 0.f;
     for (int c = 0; c < 3; ++c) maxabs = fmaxf(maxabs, fmaxf(fabsf(lo[c]), fabsf(fkey_inv(gi->bb[3 + c]))));
     gi->eps = 1e-5f + 2e-6f * maxabs;                              // ~16 ulps of the largest coordinate
