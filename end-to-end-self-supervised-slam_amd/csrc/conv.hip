@@ -211,15 +211,19 @@ __device__ __forceinline__ void epilogue_block(const ConvArgs& a, const EpiRsrc&
 
 template <bool TRANSPOSED>
 __device__ __forceinline__ int axis_src(const ConvArgs& a, int d, int k, int n_src) {      // source coordinate along one axis, -1: structural zero
+    // straight-line selects on the (wave-uniform) layer parameters: written with early returns this was a dozen exec-masked blocks per
+    // slot and ~600 of the ~1270 instructions a workgroup executed before its first load (round-3 disassembly + prologue stamps)
     if (!TRANSPOSED) {
         const int s = d * a.stride + k - a.pad;
-        if (a.pad_mode == 1) return reflect1(s, n_src);
-        return (s >= 0 && s < n_src) ? s : -1;
+        const int r = reflect1(s, n_src);
+        const bool inside = (unsigned)s < (unsigned)n_src;
+        return (a.pad_mode == 1) ? r : (inside ? s : -1);
     } else {
         const int t = d + a.off - k;
-        if (t < 0) return -1;
-        if (a.stride == 2) return ((t & 1) == 0 && (t >> 1) < n_src) ? (t >> 1) : -1;
-        return t < n_src ? t : -1;
+        const int s2 = (a.stride == 2) ? 1 : 0;
+        const int tt = t >> s2;
+        const bool ok = t >= 0 && (t & s2) == 0 && tt < n_src;
+        return ok ? tt : -1;
     }
 }
 
@@ -296,8 +300,20 @@ __device__ __forceinline__ void set_wave_priority(unsigned linear_block_id) {
 #ifdef E2E_CONV_STAMPS          // diagnostic build only (scratch/conv_stamps.py): s_memtime / s_memrealtime stamps of every workgroup's phases
 __device__ unsigned long long g_stamps[8192 * 8];
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_stamps2[8192 * 4];      // finer stamps inside the prologue of k_conv_gemm
+#define STAMP2(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 8192) g_stamps2[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// shader-clock time spent in the phases of the K loop (wave 0 of every workgroup, summed over its chunks).  The scheduling barriers pin
+// the phases, so this build runs a slightly different (more serial) schedule than the product: it locates the stalls, it is not the product's timing
+__device__ unsigned long long g_phases[8192 * 8];
+#define PHASE_DECL unsigned long long ph_last = __builtin_amdgcn_s_memtime(), ph_acc[6] = {0, 0, 0, 0, 0, 0}
+#define PHASE(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += t_ - ph_last; ph_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PHASE_WRITE do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 8192) for (int i_ = 0; i_ < 6; ++i_) g_phases[blockIdx.x * 8 + i_] = ph_acc[i_]; } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMP2(i) do { } while (0)
+#define PHASE_DECL do { } while (0)
+#define PHASE(i) do { } while (0)
+#define PHASE_WRITE do { } while (0)
 #endif
 
 template <int WM, int WN, int TM, int TN, int VEC, bool TRANSPOSED, int CB>
@@ -323,6 +339,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     const int kh0 = CLS ? ((py + a.off) & 1) : 0, kw0 = CLS ? ((px + a.off) & 1) : 0, kstep = CLS ? 2 : 1;
     const int nkh = CLS ? (a.KH - kh0 + 1) / 2 : a.KH, nkw = CLS ? (a.KW - kw0 + 1) / 2 : a.KW;
     const int64_t Ntot = (int64_t)a.B * Hc * Wc;
+    if (Ntot > 0) STAMP2(0);                                 // (diagnostic) the kernel arguments have arrived
     // non-class form: the launch's linear id -> XCD-contiguous order, decoded with (column tile, K slice) fastest and the row tile slowest
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (!CLS) {
@@ -371,6 +388,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     }
     const int sh = a.up >> 1;                                // up is 1 or 2: source coordinate = full-res coordinate >> sh
     const int Hl = a.Hs >> sh, Wl = a.Ws >> sh, C2 = a.Cin - a.C1;
+    if (ab[0] >= 0) STAMP2(1);                               // (diagnostic) rows decoded
 
     // staging registers: TWO sets -- the global loads of chunk c + 2 are issued while chunk c is multiplied and chunk c + 1 waits in the
     // other set for its turn to be written to LDS.  (One set = loads one chunk ahead left every workgroup waiting ~1.5 us per chunk for
@@ -424,6 +442,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         ld_cc = cbeg - t0 * cpt;
         set_tap();
     }
+    if (off0[0] != 1u) STAMP2(2);                            // (diagnostic) tap tables built, first tap selected
 
     auto load_chunk = [&](int chunk, int set) {
         const int kbase = chunk * CB;
@@ -500,6 +519,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     __syncthreads();
     STAMP(2);
     const int arow_l = wm * TM * 32 + (lane & 31), khalf = lane >> 5;
+    PHASE_DECL;
     // one K chunk: chunk c (in LDS buffer `BUF`) is multiplied while the loads of chunk c + 2 go to register set BUF (free: its chunk c
     // is in LDS) and chunk c + 1 -- loaded one iteration earlier into set BUF ^ 1 -- is written to the other LDS buffer afterwards
     auto chunk_step = [&](int c, auto buf_c) {
@@ -507,7 +527,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         // VEC == 4: loads and stores are UNCONDITIONAL (chunks past the end of the slice are fetched -- out-of-range offsets return zeros --
         // and written to the LDS buffer nobody reads any more): the chunk is one basic block and the scheduler may place the staging
         // instructions between the MFMAs
+        PHASE(5);                                            // (diagnostic) loop control between two chunks
         if (VEC == 4 || c + 2 < cend) load_chunk(c + 2, buf);
+        PHASE(0);                                            // (diagnostic) loads of chunk c + 2 issued, next tap selected
         // operand fragments of the WHOLE chunk are read into registers first, the MFMAs follow with counted LDS waits: hipcc's own
         // schedule of the fused loop was read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs per k-pair on ONE register set, i.e. every pair of MFMAs
         // waited for a fresh LDS round trip (~190 cycles per 128 cycles of matrix work: the kernels ran at half the MFMA rate with
@@ -532,14 +554,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x100, KH2 * (TM + TN) / 2, 0);     // all LDS reads of the batch (ds_read2: two values each) ...
             __builtin_amdgcn_sched_group_barrier(0x008, KH2 * TM * TN, 0);           // ... ahead of its MFMAs
         }
+        PHASE(1);                                            // (diagnostic) fragments read, all MFMAs of the chunk ISSUED
         if (VEC == 4 || c + 1 < cend) store_chunk(buf ^ 1, buf ^ 1);
+        PHASE(2);                                            // (diagnostic) chunk c + 1 has arrived from memory and is on its way to LDS
         __syncthreads();
+        PHASE(3);                                            // (diagnostic) barrier passed
         if (c == cbeg) STAMP(4);
     };
     for (int c = cbeg; c < cend; c += 2) {
         chunk_step(c, std::integral_constant<int, 0>{});
         if (c + 1 < cend) chunk_step(c + 1, std::integral_constant<int, 1>{});
     }
+    PHASE_WRITE;
     STAMP(3);
 
     // ---- epilogue (epilogue_block above; split-K slices store raw partial sums instead) --------------------------------------
@@ -2706,6 +2732,8 @@ int64_t e2e_conv2d_wgrad_tuned_workspace_floats(int B, int Ho, int Wo, int Cin, 
 
 #ifdef E2E_CONV_STAMPS
 int e2e_debug_read_stamps(unsigned long long* host, int n) {
+    if (n < -(1 << 20)) return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phases), (size_t)(-n - (1 << 20)) * 8);   // the K-loop phase clocks
+    if (n < 0) return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps2), (size_t)(-n) * 8);      // n < 0: the prologue stamps
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * 8);
 }
 #endif

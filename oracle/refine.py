@@ -75,7 +75,13 @@ class Refiner:
             depths = self.predict_depths(colors)
             if step == 0:
                 initial = [d.clone().detach() for d in depths]          # pre-scaling (:284-285)
+            # (test diagnostics) which element IS the lower median of the stacked predictions: the ratio's backward puts a sum over all
+            # pixels on that one element, so two evaluations that pick different (near-tied) elements have different -- equally valid --
+            # parameter gradients; tests compare those only when the element agrees
+            median_index = int(torch.cat([d.detach().reshape(-1) for d in depths]).median(0).indices)
             depths, ratio = warp_loss.median_scale(depths, gt_depths)  # (:292-298)
+            for d in depths:
+                d.retain_grad()                                        # (test diagnostics) d loss / d scaled depth, rec["g_depth"]
             self.opt.zero_grad()
             if cfg.min_reprojection or cfg.auto_masking or cfg.geometric or cfg.smoothness:
                 loss, photo = self.flagged_image_losses(depths, src, tgt, Kc, invK, T)
@@ -99,6 +105,8 @@ class Refiner:
             loss.backward()
             self.opt.step()
             rec["loss"] = loss.item()
+            rec["median_index"] = median_index
+            rec["g_depth"] = [d.grad.detach().clone() for d in depths]
             rec["depth1"] = depths[1].detach()
             rec["metrics"] = [m.item() for m in warp_loss.depth_metrics(cfg.dataset, gt_depths[0][1], depths[1][0])]
             records.append(rec)

@@ -36,7 +36,12 @@ for tile in ((64, 64, 1), (32, 64, 1)):
     st = np.zeros(n * 8, dtype=np.uint64)
     lib.e2e_debug_read_stamps(st.ctypes.data, n * 8)
     st = st.reshape(n, 8)
+    st2 = np.zeros(n * 4, dtype=np.uint64)
+    lib.e2e_debug_read_stamps(st2.ctypes.data, -n * 4)
+    st2 = st2.reshape(n, 4)
     t0 = st[:, 0].min()
+    rel2 = (st2[:, :3].astype(np.int64) - st[:, 0:1].astype(np.int64)) * 0.01
+    print("  prologue, us after the workgroup's own start: " + "  ".join(f"{nm} median {np.median(rel2[:, i]):.2f} max {rel2[:, i].max():.2f}" for i, nm in enumerate(["kernel arguments read", "rows decoded", "tap tables built"])))
     rel = (st[:, :6].astype(np.int64) - int(t0)) * 0.01          # us
     print(f"tile {tile}: {n} workgroups; launch span {rel[:, 5].max():.2f} us")
     names = ["start", "first loads issued", "prologue done (1st barrier)", "K loop done", "first chunk done", "epilogue stores landed"]
@@ -55,3 +60,25 @@ for tile in ((64, 64, 1), (32, 64, 1)):
     for c in sorted(set(cnt)):
         sel = np.isin(key, u[cnt == c])
         print(f"    CUs with {c} workgroups: K loop median {np.median(d[sel]):.2f} us, end of epilogue median {np.median(rel[sel, 5]):.2f} max {rel[sel, 5].max():.2f}")
+    ph = np.zeros(n * 8, dtype=np.uint64)
+    lib.e2e_debug_read_stamps(ph.ctypes.data, -(1 << 20) - n * 8)
+    ph = ph.reshape(n, 8)[:, :6].astype(np.float64)
+    nch = 9 * Cin // 32
+    names_ph = ["issue loads c+2 / next tap", "fragment reads + MFMA issue", "wait chunk c+1 + LDS store", "barrier", "-", "loop control"]
+    print(f"    K-loop phases, shader-clock cycles per chunk (wave 0; {nch} chunks; pinned schedule): " +
+          "  ".join(f"{nm}: {np.median(ph[:, i]) / nch:.0f}" for i, nm in enumerate(names_ph) if nm != "-") + f"  | sum {np.median(ph.sum(1)) / nch:.0f}")
+    for c in sorted(set(cnt)):
+        sel = np.isin(key, u[cnt == c])
+        print(f"      CUs with {c} workgroups: " + "  ".join(f"{np.median(ph[sel, i]) / nch:.0f}" for i in (0, 1, 2, 3, 5)))
+    print("    per XCD: workgroups, CUs, K loop median, end of epilogue median / max")
+    for xc in sorted(set(xcc)):
+        sel = xcc == xc
+        print(f"      xcc {int(xc)}: {int(sel.sum()):4d} wgs {len(set(key[sel])):3d} CUs  K loop {np.median(d[sel]):6.2f}  end {np.median(rel[sel, 5]):6.2f} / {rel[sel, 5].max():6.2f}")
+    order = np.argsort(-rel[:, 5])[:12]
+    print("    slowest workgroups: id xcc se cu wgs_on_cu | start prologue_done kloop_done end")
+    for i in order:
+        print(f"      {int(i):5d} {int(xcc[i])} {int(se[i])} {int(cu[i]):2d} {int(cnt[np.searchsorted(u, key[i])])} | {rel[i, 0]:6.2f} {rel[i, 2]:6.2f} {rel[i, 3]:6.2f} {rel[i, 5]:6.2f}")
+    slow_cu = key[order[0]]
+    print("    every workgroup of the slowest workgroup's CU:")
+    for i in np.nonzero(key == slow_cu)[0]:
+        print(f"      {int(i):5d} | {rel[i, 0]:6.2f} {rel[i, 2]:6.2f} {rel[i, 3]:6.2f} {rel[i, 5]:6.2f}")

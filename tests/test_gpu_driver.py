@@ -7,6 +7,7 @@ import torch
 from oracle import depthnet, refine
 
 pytestmark = pytest.mark.gpu
+GRAD_TOL = 1e-4          # per tensor, relative to its largest element (tests/test_gpu_network.py uses the same bound)
 
 
 def _cfg(H, W, L):
@@ -33,7 +34,8 @@ def test_first_pair_matches_reference_trajectory(golden):
     assert slam.map.M >= H * W
 
 
-def test_every_step_of_two_keyframes_vs_oracle_teacher_forced():
+@pytest.mark.parametrize("H,W", [(64, 96), (480, 640)], ids=["64x96", "480x640"])
+def test_every_step_of_two_keyframes_vs_oracle_teacher_forced(H, W):
     """Both keyframe pairs of a 3-frame sequence (the second one with the 3-D nearest-neighbour loss against the fused map), every
     refinement step against the oracle's same step: loss terms, median ratio, metrics at 1e-4 and the parameters after the step.
 
@@ -45,12 +47,16 @@ def test_every_step_of_two_keyframes_vs_oracle_teacher_forced():
     +-1e-5 differently, a few of those flips change WHICH pixel is the median, and from then on the two runs follow different
     (equally valid) paths -- measured here: plan path vs autograd path, same kernels, |w| differences of 1.5e-5 after one step
     turn into gradient differences of 0.27 in the next.  (The free-running 3-step trajectory of the first pair IS pinned, against
-    the reference's own modules: test_first_pair_matches_reference_trajectory / golden g8.)"""
+    the reference's own modules: test_first_pair_matches_reference_trajectory / golden g8; free-running GPU vs oracle over two
+    keyframes: test_two_keyframes_free_running_vs_oracle.)
+
+    480x640 = the benchmark's frame size (BASELINE configs[2]): the same six steps through the full-size launch plan -- every GEMM
+    decomposition the bench uses, the 307 200-query KNN against the fused map (oracle: C brute force), the full-size PointFusion step."""
     from e2ehip import ops
     from e2ehip.synthetic import make_sequence
     from online_adaption import SLAM
     from utils.training_utils import torch_poses_to_transforms
-    H, W, L = 64, 96, 3
+    L = 3
     seq = make_sequence(L, H, W, seed=7)
     sd = depthnet.random_state_dict(0)
     sd["decoder.decoder.10.conv.weight"] = sd["decoder.decoder.10.conv.weight"] * 40.0      # unique median element (see above)
@@ -99,7 +105,7 @@ def test_every_step_of_two_keyframes_vs_oracle_teacher_forced():
             opt._counter.fill_(snap["t"] + 1)
         sp.net.refresh_layouts()
 
-    step = 0
+    step, agreed, gstats, failures = 0, [], [], []
     for pair, (a, b) in enumerate(((0, 1), (1, 2))):
         T = torch_poses_to_transforms(poses[:, [a, b]])[0, 1]
         sp.set_pair(slam.colors[0, a], slam.colors[0, b], slam.gt_depths[0, a], slam.gt_depths[0, b], slam.intrinsics[0, 0], T, slam.poses[0, b])
@@ -122,15 +128,53 @@ def test_every_step_of_two_keyframes_vs_oracle_teacher_forced():
             np.testing.assert_allclose(total, r["loss"], rtol=1e-4)
             met = ops.depth_metrics(sp.gt[1], sp.depth[1], False).cpu().numpy()
             np.testing.assert_allclose(met, np.array(r["metrics"]), rtol=1e-4, atol=1e-6)
-            # parameters after the step: Adam's update is ~lr * sign-like for gradients at rounding level, so a small fraction of the
-            # elements may land one update apart (<= 2 lr = 2e-5); everything else agrees to fp32 rounding of the update
-            nxt, bad, tot, worst = snaps[step + 1]["w"], 0, 0, 0.0
+            # d loss / d depth of both frames (fused warp + SSIM + regulariser kernel, + the 3-D loss adjoint for the second pair) against
+            # autograd's: within 1e-4 of the largest gradient at all but a handful of pixels (<= max(4, 1e-3 N)), and 1e-4 in the L2 norm
+            # over the others.  The handful: a projection that lands within rounding of the image border (validity mask 0 / 1), of an
+            # integer coordinate (bilinear tap set) or of an SSIM clamp -- the loss is discontinuous in its gradient there, two fp32
+            # evaluations take different sides, and the difference at such a pixel is of the size of the gradient itself (measured at
+            # 480x640: 38 - 194 of 307 200 pixels of the warped frame, none of the other frame, whose only term is the regulariser)
+            for f in range(2):
+                ga, gb = sp.g_depth[f, 0].cpu(), r["g_depth"][f][0, 0]
+                err = (ga - gb).abs()
+                out = err > 1e-4 * float(gb.abs().max())
+                n_out = int(out.sum())
+                rel2 = float(((ga - gb) * ~out).norm()) / (float(gb.norm()) + 1e-30)
+                gstats.append((step, f, n_out, rel2))
+                if n_out > max(4, 1e-3 * H * W) or rel2 > 1e-4:
+                    failures.append(("g_depth", step, f, n_out, rel2))
+            # parameter gradients, recovered from Adam's first moment (m' = b1 m + (1 - b1) g with m loaded from the oracle): every tensor
+            # within GRAD_TOL of its largest element, the bound of the network-gradient tests -- here through the whole loss chain.
+            # They are compared when both sides picked the SAME element as the median of the predictions (docstring): always at 64x96
+            # (the x40 head makes it unique); among 614 400 values the neighbours of the median are ~1e-6 apart, closer than two fp32
+            # evaluations of a depth agree, so at 480x640 the element may legitimately differ (measured: it agreed in 1 step of 6, and
+            # where it did not the parameter gradients of the two sides differed by 0.9 - 2.1 x the tensor's largest element: that one
+            # element carries most of the gradient) -- then only the one-update bound holds.  At 480x640 the bound is 1e-3: the
+            # kink pixels above feed the parameter gradients (measured 3e-4).
+            md_at = set((sp.delta.reshape(-1) == sp.md).nonzero().reshape(-1).tolist())
+            same_median = r["median_index"] in md_at
+            assert same_median or (H, W) != (64, 96), (step, r["median_index"], sorted(md_at)[:4])
+            # parameters after the step: Adam's update is lr * m^ / (sqrt(v^) + eps), sign-like in the first steps; where |g| is not far
+            # above eps = 1e-8, or far below the tensor's largest gradient (relative error of g up to GRAD_TOL * max / |g|), the update
+            # amplifies rounding-level differences of g to a sizeable part of lr.  So: NO element further than one update apart
+            # (2 lr = 2e-5), and the well-conditioned elements (|g| >= 1 % of the tensor's maximum) equal to 3e-7 but for 0.2 % of them
+            nxt, cur, bad, tot, worst, gworst = snaps[step + 1], snaps[step], 0, 0, 0.0, (0.0, "")
             for kname in ora.train_keys:
-                d = (params[kname].detach().cpu() - nxt[kname]).abs()
-                bad += int((d > 2e-7).sum())
-                tot += d.numel()
+                p, o = params[kname], offs[id(params[kname])]
+                g_gpu = (opt.m[o:o + p.numel()].view_as(p).cpu() - 0.9 * cur["m"][kname]) / 0.1
+                g_ora = (nxt["m"][kname] - 0.9 * cur["m"][kname]) / 0.1
+                gmax = float(g_ora.abs().max())
+                gerr = float((g_gpu - g_ora).abs().max()) / max(gmax, 1e-30)
+                if gerr > gworst[0]:
+                    gworst = (gerr, kname)
+                d = (p.detach().cpu() - nxt["w"][kname]).abs()
+                well = g_ora.abs() >= 1e-2 * gmax
+                bad += int((d[well] > 3e-7).sum())
+                tot += int(well.sum())
                 worst = max(worst, float(d.max()))
-            assert worst <= 2.2e-5 and bad / tot < 2e-3, (step, worst, bad / tot)
+            agreed.append((same_median, gworst, worst, bad / tot))
+            if worst > 2.2e-5 or (same_median and (gworst[0] > (GRAD_TOL if (H, W) == (64, 96) else 1e-3) or bad / tot >= 2e-3)):
+                failures.append(("parameters", step, same_median, gworst, worst, bad / tot))
             step += 1
         if pair == 0:                                   # the first keyframe's map update from the same weights (index tables: test_gpu_pointfusion_knn)
             load(snaps[3])
@@ -139,7 +183,15 @@ def test_every_step_of_two_keyframes_vs_oracle_teacher_forced():
             slam._update_map(slam.colors[0, 0], slam.colors[0, 1], depth, slam.poses[0, 0], slam.poses[0, 1])
             slam.first_iter = False
             assert abs(slam.map.M - map_pair2["points"].shape[0]) <= 0.002 * slam.map.M
-            torch.testing.assert_close(slam.map.live()[0][: H * W].cpu(), map_pair2["points"][: H * W], rtol=1e-4, atol=1e-5)   # first frame's points
+            # first frame's points: the depths behind them agree to ~1e-6, which flips an association / fusion decision for an isolated
+            # point at 480x640 (with IDENTICAL inputs the tables are exact: tests/test_gpu_pointfusion_knn.py) -- allow 1e-5 of the points
+            pa, pb = slam.map.live()[0][: H * W].cpu(), map_pair2["points"][: H * W]
+            off = ((pa - pb).abs() > 1e-5 + 1e-4 * pb.abs()).any(1)
+            assert int(off.sum()) <= 1e-5 * H * W, int(off.sum())
+    print(f"[teacher forced {H}x{W}] per step (median element agreed, worst gradient error / tensor, worst parameter difference, fraction of "
+          f"well-conditioned elements beyond 3e-7): {agreed}")
+    print(f"[teacher forced {H}x{W}] d loss / d depth (step, frame, pixels beyond 1e-4 of max, relative L2 error over the others): {gstats}")
+    assert not failures, failures
 
 
 def _run_two_keyframes(mode):
