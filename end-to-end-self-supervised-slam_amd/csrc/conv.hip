@@ -555,15 +555,79 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x008, KH2 * TM * TN, 0);           // ... ahead of its MFMAs
         }
         PHASE(1);                                            // (diagnostic) fragments read, all MFMAs of the chunk ISSUED
+        // nothing moves across this point: left to itself hipcc hoists the LDS stores of chunk c + 1 (and with them the s_waitcnt vmcnt
+        // for its global loads, issued ONE step earlier) to the top of the step, ahead of 14 of the 16 MFMAs -- every step then waited
+        // for memory with the matrix pipe idle (round-3 disassembly: 1.14 us per chunk for a workgroup alone on its SIMDs, 0.43 us of
+        // it MFMA work).  Here the wait comes after the MFMAs have been issued: two steps after the loads.
+        __builtin_amdgcn_sched_barrier(0);
         if (VEC == 4 || c + 1 < cend) store_chunk(buf ^ 1, buf ^ 1);
         PHASE(2);                                            // (diagnostic) chunk c + 1 has arrived from memory and is on its way to LDS
         __syncthreads();
         PHASE(3);                                            // (diagnostic) barrier passed
         if (c == cbeg) STAMP(4);
     };
-    for (int c = cbeg; c < cend; c += 2) {
-        chunk_step(c, std::integral_constant<int, 0>{});
-        if (c + 1 < cend) chunk_step(c + 1, std::integral_constant<int, 1>{});
+    // ---- software-pipelined form (every VEC == 4 single-accumulator instantiation, i.e. every product launch) ----------------------
+    // Step c of the form above is: read chunk c's fragments -> 16 dependent MFMAs -> store chunk c + 1 -> barrier; the matrix pipe idles
+    // from the last MFMA of a step until the first fragments of the next chunk have come back from LDS (store, barrier, LDS round trip:
+    // 330 - 500 of ~1500 cycles per step, round-3 phase clocks in scratch/conv_stamps.py).  Here the barrier sits in the MIDDLE of the step
+    // and the fragments of chunk c + 1 are read under the second half of chunk c's MFMAs into a second fragment register set:
+    //   store chunk c + 1 (loaded one step ago) | MFMAs 0-7 of chunk c | barrier | read fragments of chunk c + 1 | MFMAs 8-15 of chunk c
+    // so the first MFMA of step c + 1 finds its operands in registers.  LDS stays double-buffered: buffer (c + 1) & 1 held chunk c - 1,
+    // whose fragments every wave had read before it reached the barrier of step c - 1.
+    constexpr bool PIPE = VEC == 4 && TM * TN == 1;
+    float fa[2][CB / 2], fb[2][CB / 2];
+    auto read_frags = [&](auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
+#pragma unroll
+        for (int kk = 0; kk < CB / 2; ++kk) {
+            fa[buf][kk] = As[buf][kk * 2 + khalf][arow_l];
+            fb[buf][kk] = Bs[buf][kk * 2 + khalf][wn * 32 + (lane & 31)];
+        }
+    };
+    auto pipe_step = [&](int c, auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
+        // (the scheduling barriers pin the three groups in this order; inside a group hipcc interleaves freely.  Unpinned it moved
+        // fifteen of the sixteen MFMAs behind the barrier and re-read every fragment pair right before its use)
+        load_chunk(c + 2, buf);                              // register set `buf` is free: its chunk c went to LDS a step ago
+        store_chunk(buf ^ 1, buf ^ 1);                       // chunk c + 1, loaded one step ago
+#pragma unroll
+        for (int kk = 0; kk < CB / 4; ++kk) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][kk], fb[buf][kk], acc[0][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(std::integral_constant<int, buf ^ 1>{});
+#pragma unroll
+        for (int kk = CB / 4; kk < CB / 2; ++kk) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][kk], fb[buf][kk], acc[0][0], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < CB / 4; ++g) {                   // one MFMA, then two LDS reads (ds_read2: four fragment values), eight times
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == cbeg) STAMP(4);
+    };
+    if (PIPE) {
+        if (cbeg < cend) {
+            read_frags(std::integral_constant<int, 0>{});
+            int c = cbeg;
+            for (; c + 1 < cend; c += 2) {
+                pipe_step(c, std::integral_constant<int, 0>{});
+                pipe_step(c + 1, std::integral_constant<int, 1>{});
+            }
+            if (c < cend) pipe_step(c, std::integral_constant<int, 0>{});
+        }
+    } else
+    // pairs of steps, the odd last one OUTSIDE the loop: with `if (c + 1 < cend)` around the second step inside it, the control-flow graph
+    // has an edge from the end of the first step back to the loop header, on which the four most recent loads are the ones the first step
+    // itself issued into the registers it reads its fragments into next -- hipcc's s_waitcnt insertion must cover that (impossible) path and
+    // put `s_waitcnt vmcnt(0)` at the top of EVERY first step: all prefetched loads drained before any MFMA (round-3 disassembly)
+    {
+        int c = cbeg;
+        for (; c + 1 < cend; c += 2) {
+            chunk_step(c, std::integral_constant<int, 0>{});
+            chunk_step(c + 1, std::integral_constant<int, 1>{});
+        }
+        if (c < cend) chunk_step(c, std::integral_constant<int, 0>{});
     }
     PHASE_WRITE;
     STAMP(3);
@@ -797,13 +861,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_sk(ConvArgs a, SkArgs s) {
             for (int kk = 0; kk < CB / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, CB / 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, CB / 2, 0);
+            __builtin_amdgcn_sched_barrier(0);                  // the LDS stores (and their vmcnt wait) stay behind the MFMAs: see k_conv_gemm
             store_chunk(buf ^ 1, buf ^ 1);
             __syncthreads();
         };
         if (stamp_piece == 0) STAMP(1);
-        for (int c = cb; c < ce; c += 2) {
-            chunk_step(c, std::integral_constant<int, 0>{});
-            if (c + 1 < ce) chunk_step(c + 1, std::integral_constant<int, 1>{});
+        {                                                       // (pairs + an odd tail outside the loop: see k_conv_gemm)
+            int c = cb;
+            for (; c + 1 < ce; c += 2) {
+                chunk_step(c, std::integral_constant<int, 0>{});
+                chunk_step(c + 1, std::integral_constant<int, 1>{});
+            }
+            if (c < ce) chunk_step(c, std::integral_constant<int, 0>{});
         }
         if (stamp_piece == 0) STAMP(2);
         // ---- what to do with the accumulator ------------------------------------------------------------------------------------
@@ -1344,10 +1413,16 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
     const int hw = a.Ho * a.Wo;
     const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)a.Wo;
     const bool reflect = a.pad_mode == 1;
-    f4v areg[2][A_PER], breg[2][B_PER];                      // two staging sets: loads run two chunks ahead (see k_conv_gemm)
+    // two staging sets: loads run two chunks ahead (see k_conv_gemm).  The sets hold what the loads RETURN and nothing else: the merge of
+    // the two sources of a concat layer and the ones column are applied when a set is written to LDS, two steps later -- applied at load
+    // time (the first form) they are uses of the loaded registers, i.e. an s_waitcnt vmcnt(0) right behind every load: no prefetch at all
+    // (round-3 disassembly)
+    f4v areg[2][A_PER], breg[2][B_PER], breg1[2][TWO ? B_PER : 1];
+    int left_of[2] = {0, 0};
     int ld_chunk = 0;
     auto load_chunk = [&](int set) {
         const int left = npix - ld_chunk * CB;               // pixels of the slice that remain from this chunk on (<= 0 past the end)
+        left_of[set] = left;
         const int pc = p0 + ld_chunk * CB;
         const int soffz = pc * a.Cout * 4;
 #pragma unroll
@@ -1370,14 +1445,11 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
             const bool ok = b_conv[j] && b_kr[j] < left && (reflect || inside);
             // (offset | out-of-range bit: written as `ok ? offset : OOB` the compiler sinks the offset arithmetic into an exec-masked branch)
             const unsigned o0 = (unsigned)(((b * Hl + (ys >> sh)) * Wl + (xs >> sh)) * a.C1 + b_ci[j]) * 4u;
-            f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs0, o0 | ((ok && b_src0[j]) ? 0u : OOB), 0, 0));
+            breg[set][j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs0, o0 | ((ok && b_src0[j]) ? 0u : OOB), 0, 0));
             if (TWO) {                                       // concat layer: the lanes of one load straddle the two sources
                 const unsigned o1 = (unsigned)(((b * a.Hs + ys) * a.Ws + xs) * C2 + (b_ci[j] - a.C1)) * 4u;
-                const f4v v1 = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs1, o1 | ((ok && !b_src0[j]) ? 0u : OOB), 0, 0));
-                v = b_src0[j] ? v : v1;
+                breg1[set][j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs1, o1 | ((ok && !b_src0[j]) ? 0u : OOB), 0, 0));
             }
-            const f4v ones = {(b_kr[j] < left) ? 1.f : 0.f, 0.f, 0.f, 0.f};           // ones column: dW[:, Kconv] = sum_p dZ = bias gradient
-            breg[set][j] = b_ones[j] ? ones : v;
         }
         ++ld_chunk;
     };
@@ -1390,7 +1462,10 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
             const int idx = tid + j * NT;
-            *(f4v*)&Bs[buf][b_kr[j]][(idx - b_kr[j] * (BN / 4)) * 4] = breg[set][j];
+            f4v v = breg[set][j];
+            if (TWO) v = b_src0[j] ? v : breg1[set][j];
+            const f4v ones = {(b_kr[j] < left_of[set]) ? 1.f : 0.f, 0.f, 0.f, 0.f};   // ones column: dW[:, Kconv] = sum_p dZ = bias gradient
+            *(f4v*)&Bs[buf][b_kr[j]][(idx - b_kr[j] * (BN / 4)) * 4] = b_ones[j] ? ones : v;
         }
     };
     f16v acc;
@@ -1414,12 +1489,17 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
         for (int kk = 0; kk < CB / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, CB / 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, CB / 2, 0);
+        __builtin_amdgcn_sched_barrier(0);                   // the LDS stores (and their vmcnt wait) stay behind the MFMAs: see k_conv_gemm
         store_chunk(buf ^ 1, buf ^ 1);
         __syncthreads();
     };
-    for (int c = 0; c < nchunks; c += 2) {
-        chunk_step(std::integral_constant<int, 0>{});
-        if (c + 1 < nchunks) chunk_step(std::integral_constant<int, 1>{});
+    {                                                        // (pairs + an odd tail outside the loop: see k_conv_gemm)
+        int c = 0;
+        for (; c + 1 < nchunks; c += 2) {
+            chunk_step(std::integral_constant<int, 0>{});
+            chunk_step(std::integral_constant<int, 1>{});
+        }
+        if (c < nchunks) chunk_step(std::integral_constant<int, 0>{});
     }
     float* slab = a.slabs + (int64_t)bz * a.Mpad * a.Npad;
     const int n = nn0 + wn * 32 + (lane & 31);

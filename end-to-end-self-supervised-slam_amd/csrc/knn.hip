@@ -296,11 +296,22 @@ __global__ __launch_bounds__(KT) void k_grid_scatter(const float* __restrict__ p
     }
 }
 
-__global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1, int64_t n1, GridInfo* __restrict__ gi,
+// row_len > 0: the queries are the pixels of an image of that width in row-major order (n1 a whole number of rows; width and height
+// multiples of 8, checked by the host): the 64 lanes of a wave then take an 8 x 8 pixel TILE instead of 64 consecutive pixels of a row.
+// Back-projected pixels of a tile lie within a cell or two of each other, so the lanes of a wave walk the same cell rows -- the same
+// `starts` words and the same ranges of `sorted` -- instead of a strip of the scene ~64 pixels wide.  Results are identical.
+__global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1, int64_t n1, int row_len, GridInfo* __restrict__ gi,
                                                    const unsigned int* __restrict__ starts, const float4* __restrict__ sorted,
                                                    float* __restrict__ dists, long long* __restrict__ idx,
                                                    unsigned int* __restrict__ unresolved) {
-    const int64_t i0 = (int64_t)blockIdx.x * KT + threadIdx.x;
+    int64_t i0 = (int64_t)blockIdx.x * KT + threadIdx.x;
+    if (row_len > 0) {
+        const int64_t tile = i0 >> 6;
+        const int within = (int)(i0 & 63), tiles_x = row_len >> 3;
+        const int64_t ty = tile / tiles_x;
+        const int tx = (int)(tile - ty * tiles_x);
+        i0 = (ty * 8 + (within >> 3)) * (int64_t)row_len + tx * 8 + (within & 7);
+    }
     const bool live = i0 < n1;
     const int64_t i = live ? i0 : n1 - 1;                      // idle lanes shadow the last query and write nothing
     const float x = p1[i * 3], y = p1[i * 3 + 1], z = p1[i * 3 + 2];
@@ -555,8 +566,9 @@ static void grid_build(const float* p2, int64_t n2, const long long* n2_dev, con
     hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(KT), 0, st, p2, n2, n2_dev, g.cell_of, g.starts, g.fill, g.sorted);
 }
 
-static void grid_query(const float* p1, int64_t n1, const GridWs& g, float* dists, long long* idx, hipStream_t st) {
-    hipLaunchKernelGGL(k_grid_query, dim3((unsigned)((n1 + KT - 1) / KT)), dim3(KT), 0, st, p1, n1, g.gi, g.starts, g.sorted, dists, idx, g.unresolved);
+static void grid_query(const float* p1, int64_t n1, const GridWs& g, float* dists, long long* idx, hipStream_t st, int row_len = 0) {
+    if (row_len <= 0 || (row_len & 7) || n1 % ((int64_t)row_len * 8)) row_len = 0;      // tile order needs whole 8 x 8 tiles
+    hipLaunchKernelGGL(k_grid_query, dim3((unsigned)((n1 + KT - 1) / KT)), dim3(KT), 0, st, p1, n1, row_len, g.gi, g.starts, g.sorted, dists, idx, g.unresolved);
     hipLaunchKernelGGL(k_knn1_rest, dim3(1024), dim3(KT), 0, st, p1, g.gi, g.starts, g.sorted, g.unresolved, dists, idx);
 }
 
@@ -600,6 +612,17 @@ int e2e_knn1_index_query_dev(const float* p1, int64_t n1, int64_t n2_capacity, i
     hipLaunchKernelGGL(k_grid_reset_unresolved, dim3(1), dim3(1), 0, (hipStream_t)stream, g.gi);
     grid_query(p1, n1, g, dists, idx, (hipStream_t)stream);
     E2E_LAUNCH_CHECK("e2e_knn1_index_query_dev");
+    return E2E_OK;
+}
+
+int e2e_knn1_index_query_dev_image(const float* p1, int64_t n1, int row_len, int64_t n2_capacity, int64_t max_queries, void* index, float* dists, long long* idx,
+                                   void* stream) {
+    E2E_REQUIRE(p1 && index && dists && idx && n1 > 0 && n1 <= max_queries && n2_capacity > 0 && row_len >= 0, E2E_ERR_ARG,
+                "e2e_knn1_index_query_dev_image: bad argument (n1=%lld must not exceed the max_queries=%lld the index was built for)", (long long)n1, (long long)max_queries);
+    const GridWs g = grid_ws(index, max_queries, n2_capacity, true);
+    hipLaunchKernelGGL(k_grid_reset_unresolved, dim3(1), dim3(1), 0, (hipStream_t)stream, g.gi);
+    grid_query(p1, n1, g, dists, idx, (hipStream_t)stream, row_len);
+    E2E_LAUNCH_CHECK("e2e_knn1_index_query_dev_image");
     return E2E_OK;
 }
 

@@ -286,6 +286,12 @@ int e2e_knn1_index_build_dev(const float* p2, const long long* n2_dev, int64_t n
                              void* index, void* stream);
 int e2e_knn1_index_query_dev(const float* p1, int64_t n1, int64_t n2_capacity, int64_t max_queries, void* index,
                              float* dists, long long* idx, void* stream);
+/* The same query for queries that are the pixels of an image (row-major, `row_len` pixels per row, n1 a whole number of rows -- the
+ * back-projected depth map of the 3-D loss, online_adaption.py:638-645): the lanes of a wave take 8 x 8 pixel tiles, whose points share
+ * their grid cells, instead of 64 consecutive pixels of a row.  Results are identical; row_len = 0 (or sizes that are not multiples of 8)
+ * falls back to the plain order. */
+int e2e_knn1_index_query_dev_image(const float* p1, int64_t n1, int row_len, int64_t n2_capacity, int64_t max_queries, void* index,
+                                   float* dists, long long* idx, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* disp -> depth, median scaling, regulariser, metrics, optimiser                                */

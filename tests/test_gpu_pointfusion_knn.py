@@ -278,7 +278,7 @@ def test_resident_map_step_and_index_equal_the_host_visible_forms():
     read) against FusionMap.step (host-visible size, itself checked against the oracle above): identical maps bit for bit over a 4-frame
     chain; the resident nearest-neighbour index (one capacity-sized buffer rebuilt in place from the device-resident count,
     e2e_knn1_index_build_dev) against the brute force after every frame; the sticky overflow flag."""
-    from e2ehip import ops
+    from e2ehip import _lib as L, ops
     from e2ehip.fusionmap import FusionMap
     H, W = 48, 64
     K = _K(H, W).to(DEV)
@@ -300,6 +300,18 @@ def test_resident_map_step_and_index_equal_the_host_visible_forms():
         db, ib = ops.knn1(q, b.points[: b.M].contiguous(), "brute")
         assert torch.equal(di, db) and torch.equal(ii, ib)
     assert b.knn_index(4096) is index                    # one buffer for the run
+    # image-ordered queries (e2e_knn1_index_query_dev_image: the lanes of a wave take 8 x 8 pixel tiles): same results as the plain order
+    # -- a back-projected depth image of the map's own size, and a size that is not a multiple of 8 (falls back to the plain order)
+    big = b.knn_index(H * W)
+    for hh, ww in ((H, W), (H - 3, W)):
+        qi = (torch.rand(hh * ww, 3, generator=g) * 4 - 2).to(DEV)
+        d0, i0 = torch.empty(hh * ww, device=DEV), torch.empty(hh * ww, dtype=torch.int64, device=DEV)
+        d1, i1 = torch.empty_like(d0), torch.empty_like(i0)
+        big.query(qi, hh * ww, d0, i0, L.stream())
+        big.query(qi, hh * ww, d1, i1, L.stream(), row_len=ww)
+        assert torch.equal(d0, d1) and torch.equal(i0, i1)
+        db, ib = ops.knn1(qi, b.points[: b.M].contiguous(), "brute")
+        assert torch.equal(d1, db.reshape(-1)) and torch.equal(i1, ib.reshape(-1))
     small = FusionMap(int(a.M) // 3, H, W, DEV)
     d, c = _scene(H, W, 30)
     small.step_resident(c.to(DEV), d.to(DEV), K, _pose().to(DEV))
