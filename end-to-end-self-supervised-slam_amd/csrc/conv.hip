@@ -418,6 +418,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         for (int j = 0; j < A_PER; ++j) taps.init(a, j, arow_ok[j], ab[j], ayd[j], axd[j], akq);
     }
     auto set_tap = [&]() { if (VEC == 4) taps.tap(ld_kh, ld_kw, off0, off1); };
+    // (K order: tap-major -- all channel slices of tap 0, then tap 1, ...  Walking the taps fastest instead, so that the KH x KW re-reads
+    // of a channel slice follow each other while it is still in L1 / L2, changed neither the time per layer nor the L2-fabric traffic
+    // (43.6 -> 46.2 MB per 32x128 launch): what those launches fetch is the WEIGHT matrix, once per XCD L2 -- eight times per launch --
+    // not the taps.  profiles/r03_gemm_k_order_and_fetch.txt.)
     auto advance_tap = [&]() {                               // branch-free: selects on wave-uniform values (taps past the last one of a
         const bool w1 = ++ld_cc == cpt;                      // slice are read but never multiplied)
         ld_cc = w1 ? 0 : ld_cc;
@@ -680,9 +684,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
 #endif
         return;
     }
-    // class form (3 small layers): GEMM row n = (b, yc, xc) of the class lattice -> output pixel (b, 2 yc + py, 2 xc + px); the image
-    // index by comparisons, the row by a multiplication with ceil(2^32 / Wc) (exact: rem * Wc < 2^32)
-    const unsigned hw_c = (unsigned)(Hc * Wc), mg_w = (0xFFFFFFFFu / (unsigned)Wc) + 1u;
+    // class form (3 small layers): GEMM row n = (b, yc, xc) of the class lattice -> output pixel (b, 2 yc + py, 2 xc + px), decoded like
+    // the loader's rows (reciprocal multiplication + exact fix-up; the host keeps class lattices below 2^24 rows)
+    const int hw_c = Hc * Wc;
+    const float inv_hw_c = 1.0f / (float)hw_c, inv_w_c = 1.0f / (float)Wc;
 #pragma unroll
     for (int u = 0; u < TM; ++u)
 #pragma unroll
@@ -694,9 +699,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int64_t n = n0 + (wm * TM + u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 if (n >= Ntot) continue;
-                unsigned rem = (unsigned)n, b = 0;
-                while (rem >= hw_c) { rem -= hw_c; ++b; }
-                const unsigned yc = Wc == 1 ? rem : __umulhi(rem, mg_w), xc = rem - yc * (unsigned)Wc;
+                int b, yc, xc;
+                decode_row((int)n, hw_c, Wc, inv_hw_c, inv_w_c, b, yc, xc);
                 const int64_t orow = ((int64_t)b * a.Hd + 2 * yc + py) * a.Wd + 2 * xc + px;
                 float v = fmaf(acc[u][t][r], sc, sh);
                 if (a.pre) v += a.pre[orow * a.Ncols + col];
@@ -2525,7 +2529,8 @@ static int bwd_data_impl(const float* dz, const float* w_bwd, int ld_bwd, float*
     a.Ncols = Cin; a.ldw = ld_bwd; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_mode = 0; a.act = ACT_NONE;
     // stride 2: parity classes (each input-gradient pixel only visits the taps that reach it).  A 1x1 kernel reaches one class
     // only -- the other three quarters of dxp are zeros, written by a memset node on the same stream.
-    a.cls = (stride == 2) ? 1 : 0;
+    // (class lattices of 2^24 rows or more take the plain transposed form: the class epilogue decodes its rows in fp32)
+    a.cls = (stride == 2 && (int64_t)B * ((a.Hd + 1) / 2) * ((a.Wd + 1) / 2) < (1 << 24)) ? 1 : 0;
     if (a.cls && (KH < 2 || KW < 2) && !accumulate)
         (void)hipMemsetAsync(dxp, 0, (size_t)B * a.Hd * a.Wd * Cin * sizeof(float), (hipStream_t)stream);
     // accumulate: dxp += result -- the epilogue's residual input reads the element it is about to overwrite (same thread)
