@@ -340,15 +340,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
     const int nkh = CLS ? (a.KH - kh0 + 1) / 2 : a.KH, nkw = CLS ? (a.KW - kw0 + 1) / 2 : a.KW;
     const int64_t Ntot = (int64_t)a.B * Hc * Wc;
     if (Ntot > 0) STAMP2(0);                                 // (diagnostic) the kernel arguments have arrived
-    // non-class form: the launch's linear id -> XCD-contiguous order, decoded with (column tile, K slice) fastest and the row tile slowest
+    // non-class form: the launch's linear id -> XCD-contiguous order, decoded with the column tile fastest, then the row tile, the K slice
+    // slowest: an XCD's contiguous range then covers one or two K slices, i.e. that part of the WEIGHT matrix only -- with the row tile
+    // slowest (the first form) every XCD's L2 fetched the whole matrix, eight times per launch in total (the bulk of FETCH_SIZE on the
+    // deep layers, profiles/r03_gemm_k_order_and_fetch.txt); the column tiles of a row tile, which share its input rows, stay neighbours
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (!CLS) {
-        const unsigned nyz = gridDim.y * gridDim.z;
-        const unsigned lin = xcd_contiguous(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * nyz);
-        bx = lin / nyz;
-        const unsigned rem = lin - bx * nyz;
-        bz = rem / gridDim.y;
-        by = rem - bz * gridDim.y;
+        const unsigned nxy = gridDim.x * gridDim.y;
+        const unsigned lin = xcd_contiguous(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nxy * gridDim.z);
+        bz = lin / nxy;
+        const unsigned rem = lin - bz * nxy;
+        bx = rem / gridDim.y;
+        by = rem - bx * gridDim.y;
     }
     const int64_t n0 = (int64_t)(CLS ? (bx >> 2) : bx) * BM;
     if (CLS && (n0 >= Ntot || nkh <= 0 || nkw <= 0)) return;        // classes are sized by the largest one; empty tap sets write nothing (output pre-zeroed by the host for KH < 2)
