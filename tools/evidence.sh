@@ -7,6 +7,9 @@
 #   kernel_stats.txt, timeline.txt   rocprofv3 --kernel-trace --stats of `bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-roofline`
 #   pmc_traffic.{txt,json}      tools/bench_pmc.sh (FETCH_SIZE / WRITE_SIZE passes, stamped with the source hash)
 #   gemm_tune.txt               tools/gemm_tune.py both
+#   pass_profile.txt            tools/pass_profile.py: wall time per keyframe over a whole pass + the map-size dependent entry points
+#   conv_stamps.txt             scratch/conv_stamps.py on the -DE2E_CONV_STAMPS build (if scratch/_stamped/ holds one)
+#   pytest_gpu.log              python3 -m pytest tests -m gpu -q
 export TMPDIR=/tmp
 TAG=$1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/evidence_$TAG; mkdir -p $OUT
@@ -32,4 +35,7 @@ bash tools/bench_pmc.sh $TAG > $OUT/pmc.log 2>&1
 cp gpurun_out/benchpmc_$TAG/traffic.txt $OUT/pmc_traffic.txt; cp gpurun_out/benchpmc_$TAG/traffic.json $OUT/pmc_traffic.json
 echo "pmc done" >> $OUT/progress.txt
 timeout -k 10 500 python3 tools/gemm_tune.py both > $OUT/gemm_tune.txt 2>&1; echo "tune $?" >> $OUT/progress.txt
+timeout -k 10 300 python3 tools/pass_profile.py > $OUT/pass_profile.txt 2> $OUT/pass_profile.err; echo "pass profile $?" >> $OUT/progress.txt
+if [ -f scratch/_stamped/libe2eslam_hip_stamped.so ]; then python3 scratch/conv_stamps.py 2>&1 | grep -v amdgpu.ids > $OUT/conv_stamps.txt; echo "stamps $?" >> $OUT/progress.txt; fi
+timeout -k 10 900 python3 -m pytest tests -m gpu -q --durations=5 > $OUT/pytest_gpu.log 2>&1; echo "pytest $?" >> $OUT/progress.txt
 cat $OUT/progress.txt; head -c 300 $OUT/bench_default.json; echo; head -c 300 $OUT/bench_fullpass.json; echo; head -c 300 $OUT/bench_gradicp.json
