@@ -177,7 +177,7 @@ def seq_bench(a, rank, world, dev):
     slam.set_refinement_mode()
     slam.first_iter = True
     sched = slam.keyframe_schedule()
-    if world > 1:
+    if edist.data_parallel():                            # N > 1 ranks, or the one-rank exchange rehearsal (E2E_FORCE_EXCHANGE=1)
         slam.optimizer.prebuild(slam.models["depth"].used_parameters())
     state = {"i": 0, "passes": 0, "visited": []}
 
@@ -320,7 +320,8 @@ def seq_bench(a, rank, world, dev):
                           "sequence_passes_started": state["passes"] + 1, "map_points_rank0": map_points, "map_points_per_rank": sizes,
                           "map_points_gathered": gathered, "ate_m": ate, "replicas_identical": replicas_identical, "keyframes_covered": covered,
                           "network_seed": NET_SEED, "parameter_checksum": float(slam.optimizer.flat.data.double().sum()) if slam.optimizer.flat is not None else None,
-                          "same_sequence_on_every_rank": bool(a.same_sequence)}}
+                          "same_sequence_on_every_rank": bool(a.same_sequence),
+                          "exchange_forced_on_one_rank": world == 1 and edist.data_parallel()}}
         if not replicas_identical:                      # a data-parallel run whose replicas diverged measured nothing
             out["value"] = None
             out["error"] = "replicas diverged: parameter checksums differ between ranks"
@@ -330,6 +331,8 @@ def seq_bench(a, rank, world, dev):
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
+    elif edist.data_parallel():
         dist.destroy_process_group()
     if not replicas_identical:
         sys.exit(3)
@@ -493,6 +496,10 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    elif os.environ.get("E2E_FORCE_EXCHANGE") == "1":
+        # ONE rank through the N-rank step over the real RCCL transport (e2ehip.dist.data_parallel): a correctness rehearsal, not a benchmark
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29500 + os.getpid() % 2000}", rank=0, world_size=1, device_id=dev)
     if a.workload == "warp":
         return warp_bench(a, rank, world, dev)
     return seq_bench(a, rank, world, dev)

@@ -6,12 +6,22 @@ bucket (14 319 409 trainable elements = 57.3 MB, plus a tail element that counts
 is ONE logical all-reduce with no flatten copies -- issued in two segments (exchange_gradients_late_ / _early_) so that 80 % of
 it overlaps the second half of the backward pass.
 At the end of a run the per-rank maps are gathered (variable length)."""
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def data_parallel():
+    """True when a refinement step has to go through the gradient exchange: more than one rank -- or ONE rank in an initialised
+    process group with E2E_FORCE_EXCHANGE=1.  The latter runs the N-rank step (backward split into two graphs around the two-segment
+    all-reduce, Adam as a third graph) over the REAL transport on a one-GPU box: the sum over one rank is the rank's own gradient and
+    the participant count is 1, so such a run must reproduce the plain one bit for bit (tools/rehearse_rccl_one_rank.sh)."""
+    return world() > 1 or (os.environ.get("E2E_FORCE_EXCHANGE") == "1" and dist.is_available() and dist.is_initialized())
 
 
 def _host_staged():
@@ -64,7 +74,7 @@ def exchange_gradients_(flat, participating=True):
     if not participating:
         flat.grad_ext.zero_()
     flat.grad_ext[flat.numel] = 1.0 if participating else 0.0
-    if world() > 1:
+    if data_parallel():
         _all_reduce(flat.grad_ext, dist.ReduceOp.SUM)
     return flat.grad_ext[flat.numel:flat.numel + 1]
 

@@ -162,7 +162,7 @@ class RefineStepPlan:
             cap_idx, ikey = knn_index, knn_index.ws.data_ptr()
         elif use_3d:
             self._loss3d(knn_index)
-        if edist.world() == 1:
+        if not edist.data_parallel():
             self._run(("bwd", use_3d, True, ikey), lambda: self._backward(use_3d, True, index=cap_idx))
         else:
             # data-parallel: the exchange of the bucket's tail (head, decoder, layer4: 80 % of the bytes, complete after the first

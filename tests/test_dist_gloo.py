@@ -124,3 +124,40 @@ def test_bench_spawns_one_rank_per_gpu():
     assert out["config"]["rounds"] == 3 and out["config"]["map_points_per_rank"] == [2, 3] and out["config"]["map_points_gathered"] == 5
     # step 7 (index 6) belongs to keyframe round 2: only rank 1 (2 + 1 = 3 keyframes) still participates
     assert out["config"]["participants_last_step"] == 1.0
+
+
+def _one_rank_worker(port, q):
+    sys.path[:0] = [ROOT, PKG]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from e2ehip import dist as edist
+    from e2ehip.optim import FlatParams
+    a = edist.data_parallel()                            # no process group: never
+    os.environ["E2E_FORCE_EXCHANGE"] = "1"
+    b = edist.data_parallel()                            # the switch alone is not enough either
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    c = edist.data_parallel()
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    flat = FlatParams(ps)
+    (2.0 * ps[0]).sum().backward()
+    (3.0 * ps[1]).sum().backward()
+    before = flat.grad_ext.clone()
+    split = 16
+    h = edist.exchange_gradients_late_(flat, split, True)
+    cnt = edist.exchange_gradients_early_(flat, split, h, True)
+    same = torch.equal(flat.grad_ext[: flat.numel], before[: flat.numel]) and float(cnt) == 1.0
+    del os.environ["E2E_FORCE_EXCHANGE"]
+    d = edist.data_parallel()
+    dist.destroy_process_group()
+    q.put((a, b, c, same, d))
+
+
+def test_forced_exchange_on_one_rank_is_the_identity():
+    """E2E_FORCE_EXCHANGE=1 + a process group of size 1 (tools/rehearse_rccl_one_rank.sh on the GPU box): the step takes the N-rank path,
+    and the two-segment exchange leaves the bucket as it was with a participant count of 1."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(29700 + os.getpid() % 200, q))
+    p.start()
+    res = q.get(timeout=120)
+    p.join(60)
+    assert res == (False, False, True, True, False)
