@@ -65,9 +65,13 @@ for tile in ((64, 64, 1), (32, 64, 1)):
     ph = ph.reshape(n, 8)[:, :6].astype(np.float64)
     nch = 9 * Cin // 32
     names_ph = ["issue loads c+2 / next tap", "fragment reads + MFMA issue", "wait chunk c+1 + LDS store", "barrier", "-", "loop control"]
-    print(f"    K-loop phases, shader-clock cycles per chunk (wave 0; {nch} chunks; pinned schedule): " +
+    if ph.sum() == 0:
+        print("    (K-loop phase clocks: recorded by the plain two-step loop only -- the software-pipelined loop every product launch takes has no "
+              "phase boundaries to pin; profiles/r03_conv_phase_clocks_plain_loop.txt holds the last run of the plain loop)")
+    else:
+      print(f"    K-loop phases, shader-clock cycles per chunk (wave 0; {nch} chunks; pinned schedule): " +
           "  ".join(f"{nm}: {np.median(ph[:, i]) / nch:.0f}" for i, nm in enumerate(names_ph) if nm != "-") + f"  | sum {np.median(ph.sum(1)) / nch:.0f}")
-    for c in sorted(set(cnt)):
+      for c in sorted(set(cnt)):
         sel = np.isin(key, u[cnt == c])
         print(f"      CUs with {c} workgroups: " + "  ".join(f"{np.median(ph[sel, i]) / nch:.0f}" for i in (0, 1, 2, 3, 5)))
     print("    per XCD: workgroups, CUs, K loop median, end of epilogue median / max")
