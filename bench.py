@@ -243,6 +243,7 @@ def seq_bench(a, rank, world, dev):
         conv_ms = sum(rows[n]["ms"] for n in CONV_ENTRY_POINTS if n in rows)
         conv_fl = sum(rows[n]["flops"] for n in CONV_ENTRY_POINTS if n in rows)
         conv_calls = sum(rows[n]["calls"] for n in CONV_ENTRY_POINTS if n in rows)
+        conv_bytes = sum(rows[n]["bytes"] for n in CONV_ENTRY_POINTS if n in rows)
         warp = [rows[n] for n in WARP_ENTRY_POINTS if n in rows]
         all_ms = sum(r["ms"] for r in rows.values())
         if conv_ms > 0:
@@ -264,6 +265,10 @@ def seq_bench(a, rank, world, dev):
                                            "split-K / slab reductions), fp32 v_mfma_f32_32x32x2_f32",
                 "achieved": tf, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFS, "traffic": traffic,
                 "traffic_note": traffic_note,
+                "traffic_algorithmic": conv_bytes / max(conv_calls, 1),
+                "traffic_algorithmic_note": "compulsory bytes per C-ABI convolution call: input domain + weights + result, each once (fp32); `traffic` "
+                                            "additionally holds the split-K / backward-weight slabs (written, then read by the reduction kernels) and one "
+                                            "copy of a launch's weight slices per XCD L2",
                 "launches": conv_calls, "avg_launch_us": 1e3 * conv_ms / max(conv_calls, 1), "algorithmic_gflop_per_keyframe": conv_fl / 1e9,
                 "ms_per_keyframe": conv_ms, "share_of_event_timed_kernel_time": conv_ms / all_ms,
                 "by_entry_point": {n: {"calls": rows[n]["calls"], "ms": round(rows[n]["ms"], 4), "tflops": rows[n]["flops"] / (rows[n]["ms"] * 1e-3) / 1e12}

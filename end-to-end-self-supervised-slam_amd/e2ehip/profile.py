@@ -33,6 +33,24 @@ def _conv_flops(name, a):
     return 0.0
 
 
+def _conv_bytes(name, a):
+    """Algorithmic (compulsory) HBM bytes of one convolution call: every operand once -- the gathered input domain, the weights, the
+    result -- in fp32.  (An upsampled / concatenated input counts with its gather domain B x Hs x Ws x Cin: an upper bound of what has to
+    be read; the backward-weight form reads dZ and the input and writes dW.)"""
+    if name == "e2e_conv2d_fwd":
+        B, Hs, Ws, Cin, Cout, KH, KW, stride, pad = a[10:19]
+        Ho, Wo = (Hs + 2 * pad - KH) // stride + 1, (Ws + 2 * pad - KW) // stride + 1
+    elif name in ("e2e_conv2d_bwd_data", "e2e_conv2d_bwd_data_acc", "e2e_conv2d_bwd_data_fused"):
+        B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW = a[4:13]
+    elif name == "e2e_conv2d_bwd_weight":
+        B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW = a[8:17]
+    elif name == "e2e_conv2d_bwd_weight_scaled":
+        B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW = a[9:18]
+    else:
+        return 0
+    return 4 * (B * Hs * Ws * Cin + Cout * Cin * KH * KW + B * Ho * Wo * Cout)
+
+
 def _warp_bytes(name, a):
     """Algorithmic HBM bytes of one fused warp + photometric (+ regulariser) loss-and-gradient launch:
     reads depth 4N + src 12N + tgt 12N (+ init_t, init_s, depth_s 12N), writes g_tgt 4N (+ g_src 4N)."""
@@ -79,7 +97,7 @@ class KernelTimer:
         rc = fn()
         e1.record(s)
         plain = [a.value if isinstance(a, ctypes.c_void_p) else a for a in args]
-        self.rows.append((name, e0, e1, _conv_flops(name, plain), _warp_bytes(name, plain)))
+        self.rows.append((name, e0, e1, _conv_flops(name, plain), _warp_bytes(name, plain) + _conv_bytes(name, plain)))
         return rc
 
     def summary(self):
