@@ -105,6 +105,7 @@ struct GridInfo {
     float origin[3], h, inv_h;
     int dims[3];
     unsigned int n_unresolved;
+    unsigned int n_points;     // reference points the index was built over (validates warm-start indices)
     float eps;                 // absolute slack of every geometric bound: fp32 rounding of (v - origin) * inv_h at the cloud's
 };                             // largest coordinate can move a point across a cell face by a few ulps of that coordinate
 
@@ -162,9 +163,10 @@ __global__ __launch_bounds__(KT) void k_grid_bbox(const float* __restrict__ p, i
 }
 
 __global__ __launch_bounds__(BBOX_BLOCKS) void k_grid_setup(GridInfo* gi, const unsigned int* __restrict__ part, int nparts, int gmax,
-                                                            const long long* __restrict__ nptr) {
+                                                            const long long* __restrict__ nptr, long long n_host) {
     __shared__ unsigned int sh[6][BBOX_BLOCKS / 64];
     if (nptr) gmax = (*nptr >= GRID_BIG_N2) ? GRID_MAX_BIG : GRID_MAX_SMALL;      // the host's rule (grid_max_for) on the device-resident count
+    if (threadIdx.x == 0) gi->n_points = (unsigned int)(nptr ? *nptr : n_host);
     for (int c = 0; c < 6; ++c) {
         unsigned int v = (threadIdx.x < nparts) ? part[threadIdx.x * 6 + c] : (c < 3 ? 0xFFFFFFFFu : 0u);
 #pragma unroll
@@ -300,10 +302,15 @@ __global__ __launch_bounds__(KT) void k_grid_scatter(const float* __restrict__ p
 // multiples of 8, checked by the host): the 64 lanes of a wave then take an 8 x 8 pixel TILE instead of 64 consecutive pixels of a row.
 // Back-projected pixels of a tile lie within a cell or two of each other, so the lanes of a wave walk the same cell rows -- the same
 // `starts` words and the same ranges of `sorted` -- instead of a strip of the scene ~64 pixels wide.  Results are identical.
+// warm != NULL (may alias idx): warm[i] is the answer of an EARLIER query for a point near p1[i] against the SAME reference set (the
+// refinement steps of one keyframe move a pixel's point by a fraction of a cell).  Its distance to the new query is a valid upper bound
+// -- it is a real reference point -- so the search starts with the ball already shrunk to it: cells and x-ranges beyond it are never
+// read.  The result is still the exact nearest neighbour with the lowest index among ties (the candidate only enters the same comparison
+// as every scanned point).  ref = the unsorted reference points the indices refer to.
 __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1, int64_t n1, int row_len, GridInfo* __restrict__ gi,
                                                    const unsigned int* __restrict__ starts, const float4* __restrict__ sorted,
-                                                   float* __restrict__ dists, long long* __restrict__ idx,
-                                                   unsigned int* __restrict__ unresolved) {
+                                                   float* __restrict__ dists, long long* idx,
+                                                   unsigned int* __restrict__ unresolved, const float* __restrict__ ref, const long long* warm) {
     int64_t i0 = (int64_t)blockIdx.x * KT + threadIdx.x;
     if (row_len > 0) {
         const int64_t tile = i0 >> 6;
@@ -325,6 +332,14 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
     for (int c = 0; c < 3; ++c) cq[c] = cell_coord(q[c], org[c], ih, dims[c]);
     float bd = 3.402823466e38f;
     unsigned int bi = 0xFFFFFFFFu;
+    if (warm && live) {
+        const long long w = warm[i];
+        if (w >= 0 && w < (long long)gi->n_points) {
+            const float dx = x - ref[w * 3], dy = y - ref[w * 3 + 1], dz = z - ref[w * 3 + 2];
+            bd = (dx * dx + dy * dy) + dz * dz;              // the same expression (and contraction setting) as for every scanned point
+            bi = (unsigned int)w;
+        }
+    }
     bool done = !live;
     int pl[3] = {0, 0, 0}, ph[3] = {-1, -1, -1};                  // previously explored cube (empty)
     for (int r = 0; r <= GRID_RMAX && !done; ++r) {
@@ -398,9 +413,9 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
 #pragma unroll
         for (int c = 0; c < 3; ++c) { pl[c] = lo[c]; ph[c] = hi[c]; }
     }
-    if (done && live) {
-        dists[i] = bd;
-        idx[i] = (long long)bi;
+    if (live) {                                                 // unresolved queries leave their best-so-far (a real point or nothing):
+        dists[i] = bd;                                          // k_knn1_rest starts from it instead of from scratch
+        idx[i] = (bi == 0xFFFFFFFFu) ? -1ll : (long long)bi;
     }
     // unresolved queries: ONE atomic per wave (ballot + prefix popcount), not one per lane
     const unsigned long long m = __ballot(!done);
@@ -419,8 +434,7 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
 // case every point of the grid is visited once -- the brute force this replaces read all n2 points per query.
 __global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, const GridInfo* __restrict__ gi,
                                                   const unsigned int* __restrict__ starts, const float4* __restrict__ sorted,
-                                                  const unsigned int* __restrict__ unresolved, float* __restrict__ dists,
-                                                  long long* __restrict__ idx) {
+                                                  const unsigned int* __restrict__ unresolved, float* dists, long long* idx) {
     const unsigned int cnt = gi->n_unresolved;
     const int lane = threadIdx.x & 63;
     const unsigned int wave0 = blockIdx.x * (KT / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (KT / 64);
@@ -436,6 +450,10 @@ __global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, 
 #pragma unroll
         for (int c = 0; c < 3; ++c) cq[c] = cell_coord(q[c], org[c], ih, dims[c]);
         unsigned long long best = 0xFFFFFFFFFFFFFFFFull;
+        {                                                       // what the per-lane pass (or a warm start) had found: an upper bound from a real point
+            const long long i0 = idx[i];
+            if (i0 >= 0) best = ((unsigned long long)__float_as_uint(dists[i]) << 32) | (unsigned long long)(unsigned int)i0;
+        }
         int pl[3] = {0, 0, 0}, ph[3] = {-1, -1, -1};
         int r = 0;
         while (true) {
@@ -558,7 +576,7 @@ static void grid_build(const float* p2, int64_t n2, const long long* n2_dev, con
     hipLaunchKernelGGL(k_grid_init, dim3(2048), dim3(256), 0, st, g.gi, g.counts, g.fill, g.nc);
     const int bb_blocks = gp > BBOX_BLOCKS ? BBOX_BLOCKS : gp;
     hipLaunchKernelGGL(k_grid_bbox, dim3(bb_blocks), dim3(KT), 0, st, p2, n2, n2_dev, g.bbpart);
-    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(BBOX_BLOCKS), 0, st, g.gi, g.bbpart, bb_blocks, grid_max_for(n2), n2_dev);
+    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(BBOX_BLOCKS), 0, st, g.gi, g.bbpart, bb_blocks, grid_max_for(n2), n2_dev, (long long)n2);
     hipLaunchKernelGGL(k_grid_count, dim3(gp), dim3(KT), 0, st, p2, n2, n2_dev, g.gi, g.cell_of, g.counts);
     hipLaunchKernelGGL(k_scan_blocksum, dim3(g.nb), dim3(KT), 0, st, g.counts, nscan, g.bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, g.bsum, g.nb);
@@ -566,9 +584,12 @@ static void grid_build(const float* p2, int64_t n2, const long long* n2_dev, con
     hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(KT), 0, st, p2, n2, n2_dev, g.cell_of, g.starts, g.fill, g.sorted);
 }
 
-static void grid_query(const float* p1, int64_t n1, const GridWs& g, float* dists, long long* idx, hipStream_t st, int row_len = 0) {
+static void grid_query(const float* p1, int64_t n1, const GridWs& g, float* dists, long long* idx, hipStream_t st, int row_len = 0,
+                       const float* ref = nullptr, const long long* warm = nullptr) {
     if (row_len <= 0 || (row_len & 7) || n1 % ((int64_t)row_len * 8)) row_len = 0;      // tile order needs whole 8 x 8 tiles
-    hipLaunchKernelGGL(k_grid_query, dim3((unsigned)((n1 + KT - 1) / KT)), dim3(KT), 0, st, p1, n1, row_len, g.gi, g.starts, g.sorted, dists, idx, g.unresolved);
+    if (!ref) warm = nullptr;
+    hipLaunchKernelGGL(k_grid_query, dim3((unsigned)((n1 + KT - 1) / KT)), dim3(KT), 0, st, p1, n1, row_len, g.gi, g.starts, g.sorted, dists, idx, g.unresolved, ref,
+                       warm);
     hipLaunchKernelGGL(k_knn1_rest, dim3(1024), dim3(KT), 0, st, p1, g.gi, g.starts, g.sorted, g.unresolved, dists, idx);
 }
 
@@ -623,6 +644,18 @@ int e2e_knn1_index_query_dev_image(const float* p1, int64_t n1, int row_len, int
     hipLaunchKernelGGL(k_grid_reset_unresolved, dim3(1), dim3(1), 0, (hipStream_t)stream, g.gi);
     grid_query(p1, n1, g, dists, idx, (hipStream_t)stream, row_len);
     E2E_LAUNCH_CHECK("e2e_knn1_index_query_dev_image");
+    return E2E_OK;
+}
+
+int e2e_knn1_index_query_dev_image_warm(const float* p1, int64_t n1, int row_len, const float* ref_points, const long long* warm_idx, int64_t n2_capacity,
+                                        int64_t max_queries, void* index, float* dists, long long* idx, void* stream) {
+    E2E_REQUIRE(p1 && index && dists && idx && ref_points && n1 > 0 && n1 <= max_queries && n2_capacity > 0 && row_len >= 0, E2E_ERR_ARG,
+                "e2e_knn1_index_query_dev_image_warm: bad argument (n1=%lld must not exceed the max_queries=%lld the index was built for)", (long long)n1,
+                (long long)max_queries);
+    const GridWs g = grid_ws(index, max_queries, n2_capacity, true);
+    hipLaunchKernelGGL(k_grid_reset_unresolved, dim3(1), dim3(1), 0, (hipStream_t)stream, g.gi);
+    grid_query(p1, n1, g, dists, idx, (hipStream_t)stream, row_len, ref_points, warm_idx);
+    E2E_LAUNCH_CHECK("e2e_knn1_index_query_dev_image_warm");
     return E2E_OK;
 }
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     "e2e_knn1_index_build_dev": [c_fp, c_fp, c_i64, c_i64, c_fp, c_fp],
     "e2e_knn1_index_query_dev": [c_fp, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp],
     "e2e_knn1_index_query_dev_image": [c_fp, c_i64, c_int, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp],
+    "e2e_knn1_index_query_dev_image_warm": [c_fp, c_i64, c_int, c_fp, c_fp, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp],
     "e2e_knn1_workspace_bytes": [c_i64, c_i64],
     "e2e_knn1_fwd": [c_fp, c_i64, c_fp, c_i64, c_fp, c_fp, c_fp, c_int, c_fp],
     "e2e_knn1_index_build": [c_fp, c_i64, c_i64, c_fp, c_fp],

@@ -172,9 +172,14 @@ class ResidentKnnIndex:
     def build(self):
         L.call("e2e_knn1_index_build_dev", L.ptr(self.ref), L.ptr(self.map.count), self.map.cap, self.max_queries, L.ptr(self.ws), L.stream())
 
-    def query(self, p1, n1, dists, idx, stream, row_len=0):
-        """row_len > 0: the queries are an image's pixels in row-major order (lanes take 8 x 8 tiles: e2e_knn1_index_query_dev_image)."""
-        if row_len:
+    def query(self, p1, n1, dists, idx, stream, row_len=0, warm=None):
+        """row_len > 0: the queries are an image's pixels in row-major order (lanes take 8 x 8 tiles: e2e_knn1_index_query_dev_image).
+        warm: int64 indices of an earlier query of nearby points against the same map state (may be `idx` itself): an upper bound the
+        search starts from; the result is exact either way (e2e_knn1_index_query_dev_image_warm)."""
+        if warm is not None:
+            L.call("e2e_knn1_index_query_dev_image_warm", L.ptr(p1), int(n1), int(row_len), L.ptr(self.ref), L.ptr(warm), self.map.cap, self.max_queries, L.ptr(self.ws),
+                   L.ptr(dists), L.ptr(idx), stream)
+        elif row_len:
             L.call("e2e_knn1_index_query_dev_image", L.ptr(p1), int(n1), int(row_len), self.map.cap, self.max_queries, L.ptr(self.ws), L.ptr(dists), L.ptr(idx), stream)
         else:
             L.call("e2e_knn1_index_query_dev", L.ptr(p1), int(n1), self.map.cap, self.max_queries, L.ptr(self.ws), L.ptr(dists), L.ptr(idx), stream)

@@ -394,7 +394,7 @@ class KnnIndex:
 
     resident = False
 
-    def query(self, p1, n1, dists, idx, stream, row_len=0):
+    def query(self, p1, n1, dists, idx, stream, row_len=0, warm=None):
         L.call("e2e_knn1_index_query", L.ptr(p1), int(n1), self.n2, self.max_queries, L.ptr(self.ws), L.ptr(dists), L.ptr(idx), stream)
 
 

@@ -113,7 +113,7 @@ class RefineStepPlan:
         L.call("e2e_depth_scale_fwd", L.ptr(disp), L.ptr(self.median_gt), L.ptr(self.delta), L.ptr(self.depth), L.ptr(self.md), L.ptr(self.ratio),
                L.ptr(self.ws_scale), disp.numel(), st)
 
-    def _loss3d(self, index):
+    def _loss3d(self, index, warm=False):
         """online_adaption.py:457-471 + :638-645: the target frame's cloud in world coordinates (its pose), transformed AGAIN by T
         (reference quirk), pulled to its nearest neighbours in the detached global map."""
         st, N = L.stream(), self.N
@@ -121,16 +121,17 @@ class RefineStepPlan:
         L.call("e2e_vertex_normal_maps", L.ptr(d), L.ptr(self.K), L.ptr(self.pose_tgt), float(self.alpha_den), L.ptr(self.V), L.ptr(self.Nm), L.ptr(self.Vg),
                L.ptr(self.Ng), L.ptr(self.alpha), 1, self.H, self.W, st)
         L.call("e2e_transform_points", L.ptr(self.Vg), L.ptr(self.T), L.ptr(self.moved), N, 0, st)
-        index.query(self.moved, N, self.nn_d, self.nn_idx, st, row_len=self.W)
+        # steps 2 and 3 of a keyframe: the previous step's neighbours (same pixels, same map) bound the search from the start
+        index.query(self.moved, N, self.nn_d, self.nn_idx, st, row_len=self.W, warm=self.nn_idx if warm else None)
         L.call("e2e_masked_mean_lossgrad", L.ptr(self.nn_d), L.ptr(d), N, self.w_3d, L.ptr(self.l3), L.ptr(self.g_nn), L.ptr(self.ws_aux), st)
         L.call("e2e_knn1_bwd", L.ptr(self.g_nn), L.ptr(self.moved), L.ptr(index.ref), L.ptr(self.nn_idx), N, L.ptr(self.g_moved), st)
         L.call("e2e_transform_points", L.ptr(self.g_moved), L.ptr(self.T), L.ptr(self.g_cloud), N, 1, st)
         L.call("e2e_vertex_maps_bwd", L.ptr(d), L.ptr(self.K), L.ptr(self.pose_tgt), None, L.ptr(self.g_cloud), L.ptr(self.g3), 1, self.H, self.W, st)
 
-    def _backward(self, use_3d, with_adam, late_only=False, index=None):
+    def _backward(self, use_3d, with_adam, late_only=False, index=None, warm=False):
         st = L.stream()
         if index is not None:                                       # resident index: constant launch arguments, part of the captured graph
-            self._loss3d(index)
+            self._loss3d(index, warm)
         self.loss.step()                                            # losses -> self.loss.loss[0..1]; d/d depth -> self.g_depth
         if use_3d:                                                  # g_depth_tgt += d(w_3d * l3)/d depth_tgt
             L.call("e2e_conv2d_act_bwd_acc", L.ptr(self.g3), L.ptr(self.g3), None, L.ptr(self.g_depth[1:2]), self.N, 1, 0, 1, st)
@@ -158,18 +159,19 @@ class RefineStepPlan:
         # the 3-D loss against a RESIDENT index (e2ehip.fusionmap: one buffer per run, map size on the device) has constant launch
         # arguments and rides in the backward graph; any other index object is queried eagerly here
         cap_idx, ikey = None, None
+        warm = use_3d and not first_step                            # steps 2, 3 of a keyframe: same pixels, same map as the step before
         if use_3d and getattr(knn_index, "resident", False):
-            cap_idx, ikey = knn_index, knn_index.ws.data_ptr()
+            cap_idx, ikey = knn_index, (knn_index.ws.data_ptr(), warm)
         elif use_3d:
             self._loss3d(knn_index)
         if not edist.data_parallel():
-            self._run(("bwd", use_3d, True, ikey), lambda: self._backward(use_3d, True, index=cap_idx))
+            self._run(("bwd", use_3d, True, ikey), lambda: self._backward(use_3d, True, index=cap_idx, warm=warm))
         else:
             # data-parallel: the exchange of the bucket's tail (head, decoder, layer4: 80 % of the bytes, complete after the first
             # part of the backward pass) travels while the early layers' backward computes; then the remaining 20 %, then Adam
             if self._split is None:
                 self._split = self.net.split_offset(self.opt.flat)
-            self._run(("bwd_late", use_3d, ikey), lambda: self._backward(use_3d, False, late_only=True, index=cap_idx))
+            self._run(("bwd_late", use_3d, ikey), lambda: self._backward(use_3d, False, late_only=True, index=cap_idx, warm=warm))
             handle = edist.exchange_gradients_late_(self.opt.flat, self._split, True)
             self._run("bwd_early", self.net.backward_early_layers)
             edist.exchange_gradients_early_(self.opt.flat, self._split, handle, True)

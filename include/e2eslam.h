@@ -292,6 +292,13 @@ int e2e_knn1_index_query_dev(const float* p1, int64_t n1, int64_t n2_capacity, i
  * falls back to the plain order. */
 int e2e_knn1_index_query_dev_image(const float* p1, int64_t n1, int row_len, int64_t n2_capacity, int64_t max_queries, void* index,
                                    float* dists, long long* idx, void* stream);
+/* ... with a WARM START: warm_idx[i] (NULL: none; may be the same buffer as idx) is the result of an earlier query for a point near
+ * p1[i] against the same reference set -- the three refinement steps of a keyframe (online_adaption.py:259-327) query the same pixels with
+ * slightly moved depths.  The candidate's distance bounds the search from the start; the result is still the exact nearest neighbour
+ * (lowest index among ties), whatever the candidates are -- entries outside [0, live points) are ignored.  ref_points: the reference
+ * points the index was built over (unsorted, rows of 3 floats). */
+int e2e_knn1_index_query_dev_image_warm(const float* p1, int64_t n1, int row_len, const float* ref_points, const long long* warm_idx,
+                                        int64_t n2_capacity, int64_t max_queries, void* index, float* dists, long long* idx, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* disp -> depth, median scaling, regulariser, metrics, optimiser                                */

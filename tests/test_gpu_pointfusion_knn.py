@@ -312,6 +312,15 @@ def test_resident_map_step_and_index_equal_the_host_visible_forms():
         assert torch.equal(d0, d1) and torch.equal(i0, i1)
         db, ib = ops.knn1(qi, b.points[: b.M].contiguous(), "brute")
         assert torch.equal(d1, db.reshape(-1)) and torch.equal(i1, ib.reshape(-1))
+        # warm starts (e2e_knn1_index_query_dev_image_warm): whatever the candidates -- the true neighbours of slightly moved queries (the
+        # use case: consecutive refinement steps), random valid rows, or rows outside the live map -- the result is the exact one
+        moved = qi + 0.003 * torch.randn(qi.shape, generator=g).to(DEV)
+        dm, im = ops.knn1(moved, b.points[: b.M].contiguous(), "brute")
+        for cand in (i1.clone(), torch.randint(0, int(b.M), (hh * ww,), generator=g).to(DEV), torch.full((hh * ww,), int(b.M) + 5, device=DEV),
+                     torch.full((hh * ww,), -1, dtype=torch.int64, device=DEV)):
+            dw, iw = torch.empty_like(d0), cand.clone()
+            big.query(moved, hh * ww, dw, iw, L.stream(), row_len=ww, warm=iw)          # in place, as the step plan does
+            assert torch.equal(dw, dm.reshape(-1)) and torch.equal(iw, im.reshape(-1))
     small = FusionMap(int(a.M) // 3, H, W, DEV)
     d, c = _scene(H, W, 30)
     small.step_resident(c.to(DEV), d.to(DEV), K, _pose().to(DEV))
