@@ -1483,30 +1483,46 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
     store_chunk(0, 0);
     __syncthreads();
     const int khalf = lane >> 5;
-    auto chunk_step = [&](auto buf_c) {                      // loads / stores unconditional: one basic block per chunk (see k_conv_gemm)
+    // software-pipelined step, as in k_conv_gemm: loads of chunk c + 2 and the LDS store of chunk c + 1 ride under the first half of
+    // chunk c's MFMAs, the barrier sits in the middle, the fragments of chunk c + 1 are read under the second half into the other
+    // fragment register set.  Loads / stores are unconditional (one basic block per step), steps come in pairs with the odd one behind
+    // the loop (no control-flow edge from the middle of a pair back to the loop header: see k_conv_gemm).
+    float fa[2][CB / 2], fb[2][CB / 2];
+    auto read_frags = [&](auto buf_c) {
         constexpr int buf = decltype(buf_c)::value;
-        load_chunk(buf);
-        float av[CB / 2], bv[CB / 2];
 #pragma unroll
         for (int kk = 0; kk < CB / 2; ++kk) {
-            av[kk] = As[buf][kk * 2 + khalf][wm * 32 + (lane & 31)];
-            bv[kk] = Bs[buf][kk * 2 + khalf][wn * 32 + (lane & 31)];
+            fa[buf][kk] = As[buf][kk * 2 + khalf][wm * 32 + (lane & 31)];
+            fb[buf][kk] = Bs[buf][kk * 2 + khalf][wn * 32 + (lane & 31)];
         }
-#pragma unroll
-        for (int kk = 0; kk < CB / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, CB / 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, CB / 2, 0);
-        __builtin_amdgcn_sched_barrier(0);                   // the LDS stores (and their vmcnt wait) stay behind the MFMAs: see k_conv_gemm
-        store_chunk(buf ^ 1, buf ^ 1);
-        __syncthreads();
     };
-    {                                                        // (pairs + an odd tail outside the loop: see k_conv_gemm)
+    auto pipe_step = [&](auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
+        load_chunk(buf);
+        store_chunk(buf ^ 1, buf ^ 1);
+#pragma unroll
+        for (int kk = 0; kk < CB / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][kk], fb[buf][kk], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(std::integral_constant<int, buf ^ 1>{});
+#pragma unroll
+        for (int kk = CB / 4; kk < CB / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][kk], fb[buf][kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < CB / 4; ++g) {                   // one MFMA, then two LDS reads, eight times
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (nchunks > 0) {
+        read_frags(std::integral_constant<int, 0>{});
         int c = 0;
         for (; c + 1 < nchunks; c += 2) {
-            chunk_step(std::integral_constant<int, 0>{});
-            chunk_step(std::integral_constant<int, 1>{});
+            pipe_step(std::integral_constant<int, 0>{});
+            pipe_step(std::integral_constant<int, 1>{});
         }
-        if (c < nchunks) chunk_step(std::integral_constant<int, 0>{});
+        if (c < nchunks) pipe_step(std::integral_constant<int, 0>{});
     }
     float* slab = a.slabs + (int64_t)bz * a.Mpad * a.Npad;
     const int n = nn0 + wn * 32 + (lane & 31);

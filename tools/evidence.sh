@@ -14,7 +14,12 @@ export TMPDIR=/tmp
 TAG=$1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/evidence_$TAG; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default $?" > $OUT/progress.txt
+# PMC traffic FIRST: bench.py reports roofline.traffic from profiles/r03_bench_pmc_traffic.json only if that record carries the stamp of the build it runs
+bash tools/bench_pmc.sh $TAG > $OUT/pmc.log 2>&1
+cp gpurun_out/benchpmc_$TAG/traffic.txt $OUT/pmc_traffic.txt; cp gpurun_out/benchpmc_$TAG/traffic.json $OUT/pmc_traffic.json
+cp gpurun_out/benchpmc_$TAG/traffic.json profiles/r03_bench_pmc_traffic.json
+echo "pmc done" > $OUT/progress.txt
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default $?" >> $OUT/progress.txt
 python3 bench.py --gpus 1 --steps 177 --warmup 6 --no-cpu-baseline > $OUT/bench_fullpass.json 2> $OUT/bench_fullpass.err; echo "fullpass $?" >> $OUT/progress.txt
 E2E_WGRAD_OVERLAP=1 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/bench_overlap.json 2> $OUT/bench_overlap.err; echo "overlap $?" >> $OUT/progress.txt
 timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --odom gradicp > $OUT/bench_gradicp.json 2> $OUT/bench_gradicp.err; echo "gradicp $?" >> $OUT/progress.txt
@@ -31,9 +36,6 @@ print(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 60
 for r in rows[:70]:
     print(f"{r['Name'][:90]:90s} calls {r['Calls']:>6s} avg_us {float(r['AverageNs'])/1e3:9.1f} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} {100*float(r['TotalDurationNs'])/tot:5.1f}%")
 PY
-bash tools/bench_pmc.sh $TAG > $OUT/pmc.log 2>&1
-cp gpurun_out/benchpmc_$TAG/traffic.txt $OUT/pmc_traffic.txt; cp gpurun_out/benchpmc_$TAG/traffic.json $OUT/pmc_traffic.json
-echo "pmc done" >> $OUT/progress.txt
 timeout -k 10 500 python3 tools/gemm_tune.py both > $OUT/gemm_tune.txt 2>&1; echo "tune $?" >> $OUT/progress.txt
 timeout -k 10 300 python3 tools/pass_profile.py > $OUT/pass_profile.txt 2> $OUT/pass_profile.err; echo "pass profile $?" >> $OUT/progress.txt
 if [ -f scratch/_stamped/libe2eslam_hip_stamped.so ]; then python3 scratch/conv_stamps.py 2>&1 | grep -v amdgpu.ids > $OUT/conv_stamps.txt; echo "stamps $?" >> $OUT/progress.txt; fi
