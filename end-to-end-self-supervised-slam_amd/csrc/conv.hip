@@ -262,13 +262,16 @@ struct TapTable {
     }
     // (selection by bit masks of the wave-uniform tap index: written as `k == 0 ? t[0] : ...` hipcc turns the tables into a scratch array
     // indexed at run time -- eight scratch loads per chunk)
-    __device__ __forceinline__ void tap(int kh, int kw, unsigned (&off0)[A_PER], unsigned (&off1)[A_PER]) const {
+    __device__ __forceinline__ void tap(int kh, int kw, bool two, unsigned (&off0)[A_PER], unsigned (&off1)[A_PER]) const {
         const unsigned h0 = kh == 0 ? ~0u : 0u, h1 = kh == 1 ? ~0u : 0u, h2 = kh >= 2 ? ~0u : 0u;
         const unsigned w0 = kw == 0 ? ~0u : 0u, w1 = kw == 1 ? ~0u : 0u, w2 = kw >= 2 ? ~0u : 0u;
 #pragma unroll
-        for (int j = 0; j < A_PER; ++j) {
+        for (int j = 0; j < A_PER; ++j)
             off0[j] = ((r0[j][0] & h0) | (r0[j][1] & h1) | (r0[j][2] & h2)) + ((c0[j][0] & w0) | (c0[j][1] & w1) | (c0[j][2] & w2));
-            off1[j] = ((r1[j][0] & h0) | (r1[j][1] & h1) | (r1[j][2] & h2)) + ((c1[j][0] & w0) | (c1[j][1] & w1) | (c1[j][2] & w2));
+        if (two) {                                              // (wave-uniform) only a concat layer has a second source
+#pragma unroll
+            for (int j = 0; j < A_PER; ++j)
+                off1[j] = ((r1[j][0] & h0) | (r1[j][1] & h1) | (r1[j][2] & h2)) + ((c1[j][0] & w0) | (c1[j][1] & w1) | (c1[j][2] & w2));
         }
     }
 };
@@ -420,19 +423,25 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) taps.init(a, j, arow_ok[j], ab[j], ayd[j], axd[j], akq);
     }
-    auto set_tap = [&]() { if (VEC == 4) taps.tap(ld_kh, ld_kw, off0, off1); };
+    const bool two_src = a.src1 != nullptr;
+    auto set_tap = [&]() { if (VEC == 4) taps.tap(ld_kh, ld_kw, two_src, off0, off1); };
     // (K order: tap-major -- all channel slices of tap 0, then tap 1, ...  Walking the taps fastest instead, so that the KH x KW re-reads
     // of a channel slice follow each other while it is still in L1 / L2, changed neither the time per layer nor the L2-fabric traffic
     // (43.6 -> 46.2 MB per 32x128 launch): what those launches fetch is the WEIGHT matrix, once per XCD L2 -- eight times per launch --
     // not the taps.  profiles/r03_gemm_k_order_and_fetch.txt.)
-    auto advance_tap = [&]() {                               // branch-free: selects on wave-uniform values (taps past the last one of a
-        const bool w1 = ++ld_cc == cpt;                      // slice are read but never multiplied)
+    // The vector pipe does not run under the matrix pipe of its SIMD for free: a round of three workgroups takes about its MFMA cycles PLUS
+    // its VALU cycles (3 x (16 x 64 + ~100 x 4) cycles = 1.8 us against 1.9 us measured, round-3 stamps; round 1's ablation had said
+    // T = T_valu + T_mfma).  The ~36 selects of a tap change are therefore executed only when the tap changes -- a wave-uniform branch,
+    // every Cin / CB chunks -- and the second source's half only for concat layers.  (Taps past the last one of a slice are read but
+    // never multiplied.)
+    auto advance_tap = [&]() {
+        const bool w1 = ++ld_cc == cpt;
         ld_cc = w1 ? 0 : ld_cc;
         ld_kw += w1 ? kstep : 0;
         const bool w2 = ld_kw >= a.KW;
         ld_kw = w2 ? kw0 : ld_kw;
         ld_kh += w2 ? kstep : 0;
-        set_tap();
+        if (w1) set_tap();
     };
     unsigned boff[B_PER];                                    // B tile: fixed per-thread offset, the chunk rides in soffset
 #pragma unroll
@@ -812,7 +821,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_sk(ConvArgs a, SkArgs s) {
             ld_kh = t0 / a.KW;
             ld_kw = t0 - ld_kh * a.KW;
             ld_cc = cb - t0 * cpt;
-            taps.tap(ld_kh, ld_kw, off0, off1);
+            taps.tap(ld_kh, ld_kw, a.src1 != nullptr, off0, off1);
         }
         f4v areg[2][A_PER], breg[2][B_PER];                  // two staging sets: loads run two chunks ahead (see k_conv_gemm)
         auto load_chunk = [&](int set) {
@@ -831,7 +840,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm_sk(ConvArgs a, SkArgs s) {
                 const bool w2 = ld_kw >= a.KW;
                 ld_kw = w2 ? 0 : ld_kw;
                 ld_kh += w2 ? 1 : 0;
-                taps.tap(ld_kh, ld_kw, off0, off1);
+                taps.tap(ld_kh, ld_kw, a.src1 != nullptr, off0, off1);
             }
 #pragma unroll
             for (int j = 0; j < B_PER; ++j)
