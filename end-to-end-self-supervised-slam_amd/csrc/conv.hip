@@ -227,6 +227,13 @@ __device__ __forceinline__ int axis_src(const ConvArgs& a, int d, int k, int n_s
     }
 }
 
+// a * b + c on the full-rate 24-bit multiplier (a, b < 2^24; hipcc turns `__umul24(a, b) + c` into the quarter-rate v_mad_u64_u32)
+__device__ __forceinline__ unsigned umad24(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // GEMM row n -> (image, row, column) of an (Hc x Wc) lattice without integer division: reciprocal multiplication in fp32 + exact fix-up
 // (n < 2^24, checked by the host).  A 64-bit division per slot was a third of the kernels' prologue.
 __device__ __forceinline__ void decode_row(int n, int hw, int Wc, float inv_hw, float inv_w, int& b, int& y, int& x) {
@@ -1446,24 +1453,30 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
             areg[set][j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsz, (a_kr[j] < left) ? a_off[j] : OOB, soffz, 0));
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
-            const int p = pc + b_kr[j];
-            int b = (int)((float)p * inv_hw);                // floor(p / hw) up to +-1 ...
-            b -= (b * hw > p) ? 1 : 0;                       // ... made exact
-            b += ((b + 1) * hw <= p) ? 1 : 0;
-            const int r = p - b * hw;
-            int oh = (int)((float)r * inv_wo);
-            oh -= (oh * a.Wo > r) ? 1 : 0;
-            oh += ((oh + 1) * a.Wo <= r) ? 1 : 0;
-            const int ow = r - oh * a.Wo;
-            const int ys0 = oh * a.stride + b_kh[j], xs0 = ow * a.stride + b_kw[j];
+            // (24-bit multiplies throughout: every factor is a pixel / row / channel count below 2^24 -- the host keeps P there -- and
+            // v_mul_u32_u24 / v_mad_u32_u24 issue at full rate where v_mul_lo_u32 / v_mad_u64_u32 take four times as long; this address
+            // arithmetic is NOT hidden under the MFMAs, it adds to them: 117 -> ~90 VALU per step, the quarter-rate ones gone)
+            const unsigned p = (unsigned)(pc + b_kr[j]);
+            unsigned b = (unsigned)((float)p * inv_hw);      // floor(p / hw) up to +-1 ...
+            b -= (__umul24(b, (unsigned)hw) > p) ? 1u : 0u;  // ... made exact
+            b += (__umul24(b + 1u, (unsigned)hw) <= p) ? 1u : 0u;
+            const unsigned r = p - __umul24(b, (unsigned)hw);
+            unsigned oh = (unsigned)((float)r * inv_wo);
+            oh -= (__umul24(oh, (unsigned)a.Wo) > r) ? 1u : 0u;
+            oh += (__umul24(oh + 1u, (unsigned)a.Wo) <= r) ? 1u : 0u;
+            const unsigned ow = r - __umul24(oh, (unsigned)a.Wo);
+            const int ys0 = (int)__umul24(oh, (unsigned)a.stride) + b_kh[j], xs0 = (int)__umul24(ow, (unsigned)a.stride) + b_kw[j];
             const bool inside = ys0 >= 0 && ys0 < a.Hs && xs0 >= 0 && xs0 < a.Ws;
             const int ys = reflect ? reflect1(ys0, a.Hs) : ys0, xs = reflect ? reflect1(xs0, a.Ws) : xs0;
             const bool ok = b_conv[j] && b_kr[j] < left && (reflect || inside);
-            // (offset | out-of-range bit: written as `ok ? offset : OOB` the compiler sinks the offset arithmetic into an exec-masked branch)
-            const unsigned o0 = (unsigned)(((b * Hl + (ys >> sh)) * Wl + (xs >> sh)) * a.C1 + b_ci[j]) * 4u;
+            // (offset | out-of-range bit: written as `ok ? offset : OOB` the compiler sinks the offset arithmetic into an exec-masked branch;
+            //  a structural zero may carry a negative ys / xs: its offset is garbage and never used)
+            const unsigned pix0 = umad24(umad24(b, (unsigned)Hl, (unsigned)(ys >> sh)), (unsigned)Wl, (unsigned)(xs >> sh));
+            const unsigned o0 = umad24(pix0, (unsigned)a.C1, (unsigned)b_ci[j]) * 4u;
             breg[set][j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs0, o0 | ((ok && b_src0[j]) ? 0u : OOB), 0, 0));
             if (TWO) {                                       // concat layer: the lanes of one load straddle the two sources
-                const unsigned o1 = (unsigned)(((b * a.Hs + ys) * a.Ws + xs) * C2 + (b_ci[j] - a.C1)) * 4u;
+                const unsigned pix1 = umad24(umad24(b, (unsigned)a.Hs, (unsigned)ys), (unsigned)a.Ws, (unsigned)xs);
+                const unsigned o1 = umad24(pix1, (unsigned)C2, (unsigned)(b_ci[j] - a.C1)) * 4u;
                 breg1[set][j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs1, o1 | ((ok && !b_src0[j]) ? 0u : OOB), 0, 0));
             }
         }
