@@ -2312,11 +2312,16 @@ static GemmCfg choose_cfg(int64_t rows, int cols, int K, int cb, bool allow_spli
     if (allow_split && cols > 32) {
         const int64_t tiles = ((rows + c.bm - 1) / c.bm) * ((cols + c.bn - 1) / c.bn);
         const int nchunks = (K + cb - 1) / cb;
-        // measured (tools/gemm_tune.py, profiles/r02_gemm_tune_final.txt): ~950 workgroups when the tiles alone give fewer than 500
-        // (336 tiles unsplit: 98 us, 3 slices: 70 us), never below 9 chunks of 32 per slice, never more than 12 slices; 500+ tiles
-        // run unsplit (600 tiles: 42 us, 2 slices: 47 us -- the slab round trip costs more than the fill gains)
-        int S = tiles >= 500 ? 1 : (int)((950 + tiles / 2) / tiles);
-        if (S > 12) S = 12;
+        // Round 2's rule aimed at ~950 workgroups whatever the depth.  With the round-3 loops a workgroup is cheaper to run and dearer to
+        // start and to reduce (prologue + slab round trip are now a larger share of it), and the table (tools/gemm_tune.py,
+        // profiles/r03_gemm_tune_final.txt) puts the optimum at a slice DEPTH instead: K shallower than 30 chunks of 32 runs unsplit (18
+        // chunks, 300 tiles: 25.8 us against 27.9 split in three), 36 chunks take 3 slices, 72 take 4, 144 take 6 (600 x 512 x 2304:
+        // 23.3 us at 3-4 slices, 25.1 at 6, 27.7 at the 8 the old rule picked); 500+ tiles run unsplit (600 tiles: 37 us, 2 slices: 43 us).
+        // Guards: at least ~200 workgroups where the depth allows it, never more than ~1300, never below 9 chunks per slice, at most 12 slices.
+        const int depth = nchunks * cb / 32;
+        int S = tiles >= 500 ? 1 : depth < 30 ? 1 : depth < 60 ? 3 : depth < 120 ? 4 : 6;
+        while (S < 12 && tiles * S < 200 && (nchunks / (S + 1)) * cb >= 288) ++S;
+        while (S > 1 && tiles * S > 1300) --S;
         while (S > 1 && (nchunks / S) * cb < 288) --S;
         c.S = S < 1 ? 1 : S;
     }
