@@ -1413,18 +1413,21 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
         const int m = m0 + (idx - a_kr[j] * (BM / 4)) * 4;
         a_off[j] = (m < a.Cout) ? (unsigned)(a_kr[j] * a.Cout + m) * 4u : OOB;      // Cout % 4 == 0
     }
-    // B (gathered input) slots: pixel row kr of the chunk, column quad -> (tap, ci) decoded ONCE.  The slot's pixel of chunk c is
-    // p0 + kr + c CB: its (image, row, column) are recomputed per chunk from that index with two reciprocal multiplications + an exact
-    // fix-up -- straight-line VALU code that the scheduler places between the chunk's MFMAs.  (The first form advanced (b, oh, ow)
-    // incrementally with four wrap tests per slot and branched on the padding mode and the source side: a dozen exec-masked basic
-    // blocks per chunk that ran with the matrix pipe idle.)
-    int b_kr[B_PER], b_kh[B_PER], b_kw[B_PER], b_ci[B_PER];
+    // B (gathered input) slots.  A thread's B_PER slots are B_PER column quads of ONE pixel row of the chunk (row = tid / QG, quads
+    // tid % QG + j QG): the pixel -- (image, row, column) of p0 + row + c CB -- is worked out once per thread and chunk, each slot adds its
+    // own tap (kh, kw) and channel quad, decoded ONCE here.  (Round 3 first gave every slot its own pixel: B_PER full decodes per chunk;
+    // the backward-weight GEMM issues ~12 vector instructions per MFMA and they are NOT hidden under the MFMAs -- profiles/r03_bench_pmc_sq.txt.)
+    // The pixel itself advances incrementally by CB per chunk with at most three column wraps and one row wrap -- selects, no branches --
+    // when the image is at least 11 columns and 3 rows; smaller ones re-decode it by reciprocal multiplication + exact fix-up.
+    constexpr int QG = (BN / 4) / B_PER;                     // column quads per slot group
+    static_assert(NT / QG == CB, "one pixel row of the chunk per thread");
+    const int b_row = tid / QG;
+    int b_quad[B_PER], b_kh[B_PER], b_kw[B_PER], b_ci[B_PER];
     bool b_conv[B_PER], b_ones[B_PER], b_src0[B_PER];
 #pragma unroll
     for (int j = 0; j < B_PER; ++j) {
-        const int idx = tid + j * NT;
-        b_kr[j] = idx / (BN / 4);
-        const int col = nn0 + (idx - b_kr[j] * (BN / 4)) * 4;
+        b_quad[j] = tid % QG + j * QG;
+        const int col = nn0 + b_quad[j] * 4;
         b_conv[j] = col < Kconv;
         b_ones[j] = a.has_bias && col == Kconv;
         const int tap = b_conv[j] ? col / a.Cin : 0;
@@ -1443,6 +1446,8 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
     f4v areg[2][A_PER], breg[2][B_PER], breg1[2][TWO ? B_PER : 1];
     int left_of[2] = {0, 0};
     int ld_chunk = 0;
+    int cur_b = 0, cur_oh = 0, cur_ow = 0;                   // the thread's pixel of the chunk being loaded
+    const bool incremental = a.Wo >= 11 && a.Ho >= 3;
     auto load_chunk = [&](int set) {
         const int left = npix - ld_chunk * CB;               // pixels of the slice that remain from this chunk on (<= 0 past the end)
         left_of[set] = left;
@@ -1451,12 +1456,10 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < A_PER; ++j)
             areg[set][j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsz, (a_kr[j] < left) ? a_off[j] : OOB, soffz, 0));
-#pragma unroll
-        for (int j = 0; j < B_PER; ++j) {
-            // (24-bit multiplies throughout: every factor is a pixel / row / channel count below 2^24 -- the host keeps P there -- and
-            // v_mul_u32_u24 / v_mad_u32_u24 issue at full rate where v_mul_lo_u32 / v_mad_u64_u32 take four times as long; this address
-            // arithmetic is NOT hidden under the MFMAs, it adds to them: 117 -> ~90 VALU per step, the quarter-rate ones gone)
-            const unsigned p = (unsigned)(pc + b_kr[j]);
+        // the thread's pixel of this chunk (24-bit multiplies throughout: every factor is a pixel / row / channel count below 2^24 -- the
+        // host keeps P there -- and v_mul_u32_u24 / v_mad_u32_u24 issue at full rate where v_mul_lo_u32 / v_mad_u64_u32 take four times as long)
+        if (!incremental || ld_chunk == 0) {
+            const unsigned p = (unsigned)(pc + b_row);
             unsigned b = (unsigned)((float)p * inv_hw);      // floor(p / hw) up to +-1 ...
             b -= (__umul24(b, (unsigned)hw) > p) ? 1u : 0u;  // ... made exact
             b += (__umul24(b + 1u, (unsigned)hw) <= p) ? 1u : 0u;
@@ -1464,18 +1467,33 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
             unsigned oh = (unsigned)((float)r * inv_wo);
             oh -= (__umul24(oh, (unsigned)a.Wo) > r) ? 1u : 0u;
             oh += (__umul24(oh + 1u, (unsigned)a.Wo) <= r) ? 1u : 0u;
-            const unsigned ow = r - __umul24(oh, (unsigned)a.Wo);
-            const int ys0 = (int)__umul24(oh, (unsigned)a.stride) + b_kh[j], xs0 = (int)__umul24(ow, (unsigned)a.stride) + b_kw[j];
+            cur_b = (int)b; cur_oh = (int)oh; cur_ow = (int)(r - __umul24(oh, (unsigned)a.Wo));
+        } else {                                             // + CB pixels: <= 3 column wraps (Wo >= 11), <= 1 row wrap (Ho >= 3)
+            cur_ow += CB;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const bool c = cur_ow >= a.Wo;
+                cur_ow -= c ? a.Wo : 0;
+                cur_oh += c ? 1 : 0;
+            }
+            const bool c = cur_oh >= a.Ho;
+            cur_oh -= c ? a.Ho : 0;
+            cur_b += c ? 1 : 0;
+        }
+        const int ybase = (int)__umul24((unsigned)cur_oh, (unsigned)a.stride), xbase = (int)__umul24((unsigned)cur_ow, (unsigned)a.stride);
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int ys0 = ybase + b_kh[j], xs0 = xbase + b_kw[j];
             const bool inside = ys0 >= 0 && ys0 < a.Hs && xs0 >= 0 && xs0 < a.Ws;
             const int ys = reflect ? reflect1(ys0, a.Hs) : ys0, xs = reflect ? reflect1(xs0, a.Ws) : xs0;
-            const bool ok = b_conv[j] && b_kr[j] < left && (reflect || inside);
+            const bool ok = b_conv[j] && b_row < left && (reflect || inside);
             // (offset | out-of-range bit: written as `ok ? offset : OOB` the compiler sinks the offset arithmetic into an exec-masked branch;
             //  a structural zero may carry a negative ys / xs: its offset is garbage and never used)
-            const unsigned pix0 = umad24(umad24(b, (unsigned)Hl, (unsigned)(ys >> sh)), (unsigned)Wl, (unsigned)(xs >> sh));
+            const unsigned pix0 = umad24(umad24((unsigned)cur_b, (unsigned)Hl, (unsigned)(ys >> sh)), (unsigned)Wl, (unsigned)(xs >> sh));
             const unsigned o0 = umad24(pix0, (unsigned)a.C1, (unsigned)b_ci[j]) * 4u;
             breg[set][j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs0, o0 | ((ok && b_src0[j]) ? 0u : OOB), 0, 0));
             if (TWO) {                                       // concat layer: the lanes of one load straddle the two sources
-                const unsigned pix1 = umad24(umad24(b, (unsigned)a.Hs, (unsigned)ys), (unsigned)a.Ws, (unsigned)xs);
+                const unsigned pix1 = umad24(umad24((unsigned)cur_b, (unsigned)a.Hs, (unsigned)ys), (unsigned)a.Ws, (unsigned)xs);
                 const unsigned o1 = umad24(pix1, (unsigned)C2, (unsigned)(b_ci[j] - a.C1)) * 4u;
                 breg1[set][j] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs1, o1 | ((ok && !b_src0[j]) ? 0u : OOB), 0, 0));
             }
@@ -1490,11 +1508,10 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
-            const int idx = tid + j * NT;
             f4v v = breg[set][j];
             if (TWO) v = b_src0[j] ? v : breg1[set][j];
-            const f4v ones = {(b_kr[j] < left_of[set]) ? 1.f : 0.f, 0.f, 0.f, 0.f};   // ones column: dW[:, Kconv] = sum_p dZ = bias gradient
-            *(f4v*)&Bs[buf][b_kr[j]][(idx - b_kr[j] * (BN / 4)) * 4] = b_ones[j] ? ones : v;
+            const f4v ones = {(b_row < left_of[set]) ? 1.f : 0.f, 0.f, 0.f, 0.f};     // ones column: dW[:, Kconv] = sum_p dZ = bias gradient
+            *(f4v*)&Bs[buf][b_row][b_quad[j] * 4] = b_ones[j] ? ones : v;
         }
     };
     f16v acc;
