@@ -1419,6 +1419,7 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
     // the backward-weight GEMM issues ~12 vector instructions per MFMA and they are NOT hidden under the MFMAs -- profiles/r03_bench_pmc_sq.txt.)
     // The pixel itself advances incrementally by CB per chunk with at most three column wraps and one row wrap -- selects, no branches --
     // when the image is at least 11 columns and 3 rows; smaller ones re-decode it by reciprocal multiplication + exact fix-up.
+    const float inv_cin = 1.0f / (float)a.Cin, inv_kw = 1.0f / (float)a.KW;
     constexpr int QG = (BN / 4) / B_PER;                     // column quads per slot group
     static_assert(NT / QG == CB, "one pixel row of the chunk per thread");
     const int b_row = tid / QG;
@@ -1430,11 +1431,18 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
         const int col = nn0 + b_quad[j] * 4;
         b_conv[j] = col < Kconv;
         b_ones[j] = a.has_bias && col == Kconv;
-        const int tap = b_conv[j] ? col / a.Cin : 0;
-        b_ci[j] = b_conv[j] ? col - tap * a.Cin : 0;
+        // (col < 2^24: quotients by reciprocal multiplication + exact fix-up instead of two 32-bit integer divisions per slot)
+        const int cc = b_conv[j] ? col : 0;
+        int tap = (int)((float)cc * inv_cin);
+        tap -= (tap * a.Cin > cc) ? 1 : 0;
+        tap += ((tap + 1) * a.Cin <= cc) ? 1 : 0;
+        b_ci[j] = cc - tap * a.Cin;
         b_src0[j] = b_ci[j] < a.C1;
-        b_kh[j] = tap / a.KW - a.pad;                        // tap offset relative to the strided output position
-        b_kw[j] = tap - (tap / a.KW) * a.KW - a.pad;
+        int tkh = (int)((float)tap * inv_kw);
+        tkh -= (tkh * a.KW > tap) ? 1 : 0;
+        tkh += ((tkh + 1) * a.KW <= tap) ? 1 : 0;
+        b_kh[j] = tkh - a.pad;                               // tap offset relative to the strided output position
+        b_kw[j] = tap - tkh * a.KW - a.pad;
     }
     const int hw = a.Ho * a.Wo;
     const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)a.Wo;
@@ -1563,12 +1571,20 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
         }
         if (c < nchunks) pipe_step(std::integral_constant<int, 0>{});
     }
-    float* slab = a.slabs + (int64_t)bz * a.Mpad * a.Npad;
-    const int n = nn0 + wn * 32 + (lane & 31);
+    // slab store through a buffer resource: one 32-bit lane offset (beyond num_records where the tile overhangs the slab), the row of
+    // accumulator element r in the scalar offset -- 16 stores and a handful of address instructions instead of 16 exec-masked blocks with
+    // 64-bit pointer arithmetic each (the backward-weight kernel is the VALU-heaviest one: profiles/r03_bench_pmc_sq.txt)
+    {
+        const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.slabs + (int64_t)bz * a.Mpad * a.Npad), 0, a.Mpad * a.Npad * 4, 0x00020000);
+        const int n = nn0 + wn * 32 + (lane & 31), mb = m0 + wm * 32 + 4 * khalf;
+        const int rows_left = a.Mpad - mb;                   // rows of this lane's 32-row block that exist (the range check ignores soffset)
+        const unsigned voff = (n < a.Npad && rows_left > 0) ? (unsigned)(mb * a.Npad + n) * 4u : OOB;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (m < a.Mpad && n < a.Npad) slab[(int64_t)m * a.Npad + n] = acc[r];
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            const float v = acc[r];                          // (a scalar copy first: __builtin_bit_cast applied to the vector ELEMENT stored element 0 sixteen times)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsl, (dr < rows_left) ? voff : OOB, dr * a.Npad * 4, 0);
+        }
     }
 }
 
