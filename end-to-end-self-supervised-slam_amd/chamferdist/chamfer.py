@@ -42,7 +42,7 @@ class ChamferDistance(nn.Module):
         red = torch.mean if reduction == "mean" else torch.sum
 
         def one_way(a, b):
-            return red(knn_points(a, b.detach()).dists[..., 0], dim=1)
+            return red(knn_points(a, b).dists[..., 0], dim=1)          # gradients to BOTH clouds, as chamferdist's knn_points
 
         fwd = one_way(source_cloud, target_cloud)
         bwd = one_way(target_cloud, source_cloud) if (bidirectional or reverse) else None

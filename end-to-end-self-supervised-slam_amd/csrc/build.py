@@ -4,9 +4,13 @@
     python end-to-end-self-supervised-slam_amd/csrc/build.py [--force] [--asm]
 
 Objects land in csrc/_obj/, the shared library in ../lib/libe2eslam_hip.so (git-ignored; it
-travels to the GPU box with the repo snapshot).  -ffp-contract=off: the association / fusion
-kernels must evaluate fp32 expressions exactly as the CPU oracle does (no implicit FMA); where a
-fused multiply-add is wanted the source says fmaf().
+travels to the GPU box with the repo snapshot).
+
+Floating-point contraction is decided per file.  pointfusion.hip / knn.hip / icp.hip produce index tables, masks and
+nearest-neighbour results that are compared BIT FOR BIT with the CPU oracle: they must evaluate fp32 expressions exactly as
+written (-ffp-contract=off; where a fused multiply-add is wanted the source says fmaf()).  Everything else is compared within
+a floating-point tolerance and is VALU-bound in places (the fused warp + photometric kernel issues ~740 vector instructions per
+64 pixels): there the compiler may contract a * b + c into v_fma_f32 (-ffp-contract=fast, hipcc's default for device code).
 """
 import concurrent.futures as cf
 import os
@@ -18,8 +22,12 @@ OBJ = os.path.join(HERE, "_obj")
 LIBDIR = os.path.join(os.path.dirname(HERE), "lib")
 LIB = os.path.join(LIBDIR, "libe2eslam_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++17", "-Wall",
-         "-Wno-unused-function", "-Wno-unused-result"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+EXACT = {"pointfusion.hip", "knn.hip", "icp.hip"}          # bit-exact against the oracle: no implicit FMA
+
+
+def flags_for(src):
+    return FLAGS + ["-ffp-contract=off" if src in EXACT else "-ffp-contract=fast"]
 
 
 def sources():
@@ -35,9 +43,9 @@ def newest_header():
 def compile_one(src, force, asm):
     obj = os.path.join(OBJ, src + ".o")
     sp = os.path.join(HERE, src)
-    if (not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), newest_header())):
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), newest_header(), os.path.getmtime(os.path.abspath(__file__)))):
         return obj, ""
-    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+    cmd = [HIPCC] + flags_for(src) + ["-x", "hip", "-c", sp, "-o", obj]
     if asm:
         cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     r = subprocess.run(cmd, capture_output=True, text=True)

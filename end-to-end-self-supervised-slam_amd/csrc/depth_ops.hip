@@ -304,6 +304,7 @@ static inline int sgrid(int64_t n, int cap = 1024) {
 extern "C" {
 
 int64_t e2e_median_workspace_bytes(void) { return (3 * MED_BINS + 8) * 4; }
+int64_t e2e_median_index_offset_bytes(void) { return (3 * MED_BINS + 3) * 4; }     /* MedState::index */
 
 int e2e_median_lower(const float* x, int64_t n, float* value_out, void* workspace, void* stream) {
     E2E_REQUIRE(n > 0 && n < 0xFFFFFFFFll && x && value_out && workspace, E2E_ERR_ARG, "e2e_median_lower: bad argument");

@@ -75,6 +75,28 @@ __global__ __launch_bounds__(KT) void k_knn1_bwd(const float* __restrict__ g, co
     }
 }
 
+// gradient wrt the REFERENCE cloud: g_p2[idx[i]] += -2 g[i] (p1[i] - p2[idx[i]]) -- a scatter with collisions (several queries share a
+// neighbour), accumulated as 2^-48 fixed-point integers so that the sum does not depend on the arrival order (bitwise reproducible;
+// |sum| < 32768).  A contribution that is not finite or >= 4096 is refused and poisons the result (NaN everywhere) instead of wrapping.
+__global__ __launch_bounds__(KT) void k_knn1_bwd_ref(const float* __restrict__ g, const float* __restrict__ p1, const float* __restrict__ p2,
+                                                     const long long* __restrict__ idx, int64_t n1, int64_t n2, unsigned long long* __restrict__ fx) {
+    for (int64_t i = (int64_t)blockIdx.x * KT + threadIdx.x; i < n1; i += (int64_t)gridDim.x * KT) {
+        const long long j = idx[i];
+        const float gi = -2.f * g[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = gi * (p1[i * 3 + c] - p2[j * 3 + c]);
+            if (fabsf(v) < 4096.f) atomicAdd(fx + j * 3 + c, (unsigned long long)__double2ll_rn((double)v * 281474976710656.0));
+            else atomicOr(fx + n2 * 3, 1ull);
+        }
+    }
+}
+__global__ void k_knn1_fixed48_to_float(const long long* __restrict__ fx, float* __restrict__ out, int64_t n) {
+    const bool poisoned = fx[n] != 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = poisoned ? __uint_as_float(0x7FC00000u) : (float)((double)fx[i] * (1.0 / 281474976710656.0));
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // Exact uniform-grid acceleration (results identical to the brute force, ties included).
@@ -704,6 +726,19 @@ int e2e_knn1_bwd(const float* g_dists, const float* p1, const float* p2, const l
     const int qblocks = (int)((n1 + KT - 1) / KT);
     hipLaunchKernelGGL(k_knn1_bwd, dim3((unsigned)(qblocks > 4096 ? 4096 : qblocks)), dim3(KT), 0, (hipStream_t)stream, g_dists, p1, p2, idx, n1, g_p1);
     E2E_LAUNCH_CHECK("e2e_knn1_bwd");
+    return E2E_OK;
+}
+
+int e2e_knn1_bwd_ref(const float* g_dists, const float* p1, const float* p2, const long long* idx, int64_t n1, int64_t n2, long long* scratch_fixed,
+                     float* g_p2, void* stream) {
+    E2E_REQUIRE(n1 > 0 && n2 > 0 && g_dists && p1 && p2 && idx && scratch_fixed && g_p2, E2E_ERR_ARG, "e2e_knn1_bwd_ref: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    E2E_REQUIRE(hipMemsetAsync(scratch_fixed, 0, (size_t)(3 * n2 + 1) * sizeof(long long), st) == hipSuccess, E2E_ERR_LAUNCH,
+                "e2e_knn1_bwd_ref: hipMemsetAsync of the fixed-point scratch failed");
+    const int64_t qb = (n1 + KT - 1) / KT, cb = (3 * n2 + 255) / 256;
+    hipLaunchKernelGGL(k_knn1_bwd_ref, dim3((unsigned)(qb > 4096 ? 4096 : qb)), dim3(KT), 0, st, g_dists, p1, p2, idx, n1, n2, (unsigned long long*)scratch_fixed);
+    hipLaunchKernelGGL(k_knn1_fixed48_to_float, dim3((unsigned)(cb > 4096 ? 4096 : cb)), dim3(256), 0, st, scratch_fixed, g_p2, 3 * n2);
+    E2E_LAUNCH_CHECK("e2e_knn1_bwd_ref");
     return E2E_OK;
 }
 

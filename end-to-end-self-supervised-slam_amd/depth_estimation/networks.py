@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from e2ehip import conv as _e2e_conv
 from e2ehip import nn_ops
 
 
@@ -35,11 +36,12 @@ class _ConvBN(nn.Module):
         Train-mode BatchNorm (batch statistics + running-average update): the reference only switches to eval() when
         MODEL.refinement_mode is set (online_adaption.py:175-184, train_depth.py:246-247); with the flag off the network stays in train
         mode.  That configuration is NOT the benchmarked path and has no native kernel: the convolution runs on the HIP kernel
-        and the normalisation itself goes through torch.nn.functional.batch_norm -- the one place where an ATen operator computes
+        and the normalisation itself goes through the nn.BatchNorm2d module (running statistics, num_batches_tracked and the
+        momentum=None cumulative average exactly as in the reference's modules) -- the one place where an ATen operator computes
         on behalf of the network ("train-mode BatchNorm")."""
         if bn.training:
             y = nn_ops.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0], "zeros", None, None, in_norm=in_norm)
-            y = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
+            y = bn(y)       # the MODULE, not F.batch_norm: num_batches_tracked advances and momentum=None means the cumulative average
             if residual is not None:
                 y = y + residual
             return torch.relu(y) if relu else y
@@ -157,6 +159,7 @@ class ResnetEncoder(nn.Module):
             self.encoder = ResNet(*_CFG[num_layers])
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
+        self._layout_group = _e2e_conv.group_layouts(self)      # GEMM copies of this model's weights are refreshed together (one launch)
 
     def forward(self, input_image):
         """(B,H,W,3) channels-last image in [0,1] -> the five feature maps (NCHW shape, NHWC memory)."""
@@ -238,6 +241,7 @@ class _DecoderBase(nn.Module):
             self.convs[("dispconv", s)] = Conv3x3(self.num_ch_dec[s], self.num_output_channels)
         self.decoder = nn.ModuleList(list(self.convs.values()))
         self.sigmoid = nn.Sigmoid()
+        self._layout_group = _e2e_conv.group_layouts(self)
 
     def _trunk(self, input_features):
         x = input_features[-1]
@@ -279,6 +283,7 @@ class DispResNet_Indoor(nn.Module):
         super().__init__()
         self.encoder = ResnetEncoder(num_layers=num_layers, pretrained=pretrained, num_input_images=1)
         self.decoder = Indoor_DepthDecoder(self.encoder.num_ch_enc)
+        self._layout_group = _e2e_conv.group_layouts(self)      # encoder + decoder as ONE group (supersedes the two built above)
 
     def init_weights(self):
         pass

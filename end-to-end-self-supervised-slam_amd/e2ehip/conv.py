@@ -2,7 +2,6 @@
 (stride, zero / reflection padding, nearest x2 upsample + channel concat) and the epilogue (folded eval-BN /
 bias, residual add, ReLU / ELU / disparity head) fused.  Tensors are NCHW-shaped, channels_last in memory."""
 import ctypes
-import weakref
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -12,52 +11,71 @@ from . import _lib as L
 ACT = {None: 0, "relu": 1, "elu": 2, "disp": 3}
 CL = torch.channels_last
 
-# k-major GEMM copies of the weights, cached until the weights change.  A weight tensor changes either through torch
-# (its _version counter moves) or through FusedAdam's raw-pointer kernel, which bumps WEIGHT_EPOCH.
-WEIGHT_EPOCH = [0]
+# ---- state -------------------------------------------------------------------------------------------------------------------
+# This module keeps NO process-wide state.  Everything that outlives a call hangs on the objects it describes:
+#   * a weight's k-major GEMM copies: `w._e2e_layouts` on the Parameter itself (dies with it);
+#   * the set of weights refreshed together: a LayoutGroup owned by ONE model (group_layouts), holding its members strongly;
+#   * "an optimiser rewrote these parameters behind torch's version counters": a counter cell owned by that optimiser's
+#     FlatParams and shared by its parameters (`p._e2e_epoch`);
+#   * "backward-weight kernels may write straight into the optimiser's flat bucket", and the side stream those chains use:
+#     fields of that FlatParams (`p._e2e_grad_owner`), switched on for the extent of ONE backward by direct_weight_grads();
+#   * a forced GEMM decomposition (tests, tools): the `tuning` argument of conv2d().
+# Round 3 kept a module-level registry of every weight of every model ever built and refreshed all of them in one launch from a
+# table of raw device pointers; a dead model collected by the garbage collector between the pointer walk and the launch left
+# the kernel writing into blocks the allocator had already handed out again ("the order-dependent test failures").
 
 
-# Gradient sinks.  FusedAdam keeps every gradient in one flat buffer; inside `direct_weight_grads()` the backward-weight
-# kernels ACCUMULATE straight into a parameter's slice of that buffer (`p._e2e_grad_sink`, installed by FlatParams) and
-# return no gradient for it, which removes one AccumulateGrad add kernel per parameter and step (48 at 5 us).  Off by
-# default: torch.autograd.grad() callers must get their gradients returned.
-DIRECT_WGRAD = [False]
+def epoch_of(p):
+    """How often an optimiser has rewritten parameter p through a raw pointer (0: never / torch optimisers, whose in-place
+    updates move p._version instead)."""
+    cell = getattr(p, "_e2e_epoch", None)
+    return cell[0] if cell is not None else 0
 
 
-_SIDE = {}              # device -> stream that runs the backward-weight chains of direct_weight_grads(overlap=True)
+def epoch_sum(params):
+    """Monotone stamp over the (distinct) epoch cells of several parameters."""
+    cells = {}
+    for p in params:
+        c = getattr(p, "_e2e_epoch", None)
+        if c is not None:
+            cells[id(c)] = c
+    return sum(c[0] for c in cells.values())
 
 
 class direct_weight_grads:
-    """overlap=True additionally moves every backward-weight chain (GEMM + slab folds + reduce) to a second stream: it
-    depends only on dZ, like the backward-data GEMM next to it, and two half-empty MFMA kernels side by side fill the
-    SIMDs better than one after the other.  The context exit joins the streams."""
+    """with direct_weight_grads(optimizer, overlap): inside, the backward-weight kernels ACCUMULATE straight into the parameters'
+    slices of the optimiser's flat gradient bucket and autograd gets no gradient for them (one AccumulateGrad add kernel less per
+    parameter and step: 48 at 5 us).  The switch is a field of THAT optimiser's FlatParams -- another model's backward running
+    meanwhile is not affected -- and it is off outside the block: torch.autograd.grad() callers get their gradients returned.
+    An optimiser without a flat bucket (torch's own, or FusedAdam before its first step): a no-op.
+    overlap=True additionally moves every backward-weight chain (GEMM + slab folds + reduce) to the FlatParams' side stream: it
+    depends only on dZ, like the backward-data GEMM next to it.  The exit joins the streams."""
 
-    def __init__(self, overlap=False):
-        self.overlap = overlap
+    def __init__(self, optimizer, overlap=False):
+        self.flat = getattr(optimizer, "flat", None)
+        self.overlap = bool(overlap)
 
     def __enter__(self):
-        self.prev = (DIRECT_WGRAD[0], OVERLAP[0])
-        DIRECT_WGRAD[0] = True
-        OVERLAP[0] = self.overlap
+        f = self.flat
+        if f is not None:
+            self.prev = (f.direct, f.overlap)
+            f.direct, f.overlap = True, self.overlap
+        return self
 
     def __exit__(self, *exc):
-        DIRECT_WGRAD[0], OVERLAP[0] = self.prev
-        for side in _SIDE.values():
-            torch.cuda.current_stream(side.device).wait_stream(side)
-
-
-OVERLAP = [False]
-
-
-def _side_stream(dev):
-    s = _SIDE.get(dev)
-    if s is None:
-        s = _SIDE[dev] = torch.cuda.Stream(dev)
-    return s
+        f = self.flat
+        if f is not None:
+            f.direct, f.overlap = self.prev
+            if f.side is not None:
+                torch.cuda.current_stream(f.side.device).wait_stream(f.side)
 
 
 def _sink(param, shape):
-    if not DIRECT_WGRAD[0] or param is None:
+    """The parameter's slice of its optimiser's flat gradient bucket while direct_weight_grads() is active for that optimiser."""
+    if param is None:
+        return None
+    owner = getattr(param, "_e2e_grad_owner", None)
+    if owner is None or not owner.direct:
         return None
     t = getattr(param, "_e2e_grad_sink", None)
     if t is None or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or t.dtype != torch.float32:
@@ -65,26 +83,62 @@ def _sink(param, shape):
     return t
 
 
-_REGISTRY = []          # weak references to every weight that owns layout buffers
-_DESC = {}              # device -> (signature of the table, device tensor of descriptors)
+def _overlap_stream(param):
+    """Side stream for the backward-weight chain of `param` (None: same stream)."""
+    owner = getattr(param, "_e2e_grad_owner", None)
+    if owner is None or not (owner.direct and owner.overlap):
+        return None
+    return owner.side_stream()
+
+
+class LayoutGroup:
+    """The convolution weights of ONE model whose GEMM layouts are refreshed together: after an optimiser step every one is stale,
+    and one launch over a descriptor table replaces ~40.  The group holds its members strongly and is owned by the model
+    (weight -> group -> weights is an ordinary reference cycle inside the model): every pointer that goes into a table belongs to
+    a tensor that is alive for as long as the caller -- a forward of that model -- runs."""
+
+    def __init__(self):
+        self.members = []
+        self._sig = self._desc = None
+
+    def add(self, w):
+        old = getattr(w, "_e2e_group", None)
+        if old is self:
+            return
+        if old is not None:
+            old.members = [m for m in old.members if m is not w]
+            old._sig = old._desc = None
+        w._e2e_group = self
+        self.members.append(w)
+
+
+def group_layouts(module):
+    """Put every MFMA-path convolution weight of `module` into one LayoutGroup (the outermost model that calls this wins)."""
+    g = LayoutGroup()
+    for m in module.modules():
+        if isinstance(m, torch.nn.Conv2d) and m.weight.shape[0] % 16 == 0:
+            g.add(m.weight)
+    return g
+
+
+def _layout_key(w):
+    return (w.data_ptr(), w._version, epoch_of(w))
 
 
 def _weight_layouts(w, want_bwd):
     """k-major GEMM copies of a weight.  The entry lives ON the weight tensor object (a recycled allocation of another
-    tensor can never alias it) and is valid while (data_ptr, torch version counter, FusedAdam epoch) are unchanged.
-    The buffers are allocated once and rewritten in place; when an entry is stale, EVERY stale registered weight on the
-    device is refreshed in the same launch (after an optimiser step that is all of them: 1 launch instead of ~40)."""
-    key = (w.data_ptr(), w._version, WEIGHT_EPOCH[0])
+    tensor can never alias it) and is valid while (data_ptr, torch version counter, optimiser epoch) are unchanged.
+    The buffers are allocated once and rewritten in place; when an entry is stale, the stale weights of the SAME LayoutGroup
+    (= the same model) are refreshed in the same launch."""
     ent = getattr(w, "_e2e_layouts", None)
-    if ent is not None and ent["key"] == key and (ent["wb"] is not None or not want_bwd):
+    if ent is not None and ent["key"] == _layout_key(w) and ent["wf"].device == w.device and (ent["wb"] is not None or not want_bwd):
         return ent["wf"], ent["wb"]
     Cout, Cin, KH, KW = w.shape
     ldf, ldb = _ld(Cout), _ld(Cin)
-    if ent is None:
+    if ent is None or ent["wf"].device != w.device:
         ent = {"key": None, "wf": torch.zeros(KH * KW * Cin, ldf, device=w.device, dtype=torch.float32), "wb": None}
         try:
             w._e2e_layouts = ent
-            _REGISTRY.append(weakref.ref(w))
         except AttributeError:                      # cannot attach (exotic tensor subclass): uncached single refresh
             wb = torch.zeros(KH * KW * Cout, ldb, device=w.device, dtype=torch.float32) if want_bwd else None
             L.call("e2e_conv_weight_layouts", L.ptr(w), Cout, Cin, KH, KW, L.ptr(ent["wf"]), ldf, L.ptr(wb), ldb, L.stream())
@@ -92,35 +146,41 @@ def _weight_layouts(w, want_bwd):
     if want_bwd and ent["wb"] is None:
         ent["wb"] = torch.zeros(KH * KW * Cout, ldb, device=w.device, dtype=torch.float32)
         ent["key"] = None
-    _refresh_stale(w.device)
+    grp = getattr(w, "_e2e_group", None)
+    _refresh_stale(w, grp)
     return ent["wf"], ent["wb"]
 
 
-def _refresh_stale(device):
-    rows, sig, live = [], [], []
-    for r in _REGISTRY:
-        t = r()
-        if t is None:
+def _refresh_stale(w, grp):
+    """Rewrite the layouts of `w` and of the stale members of its group.  `todo` keeps every tensor whose pointer goes into the
+    table strongly referenced until after the launch (stream order covers everything later)."""
+    cand = [w] if grp is None else ([w] + [m for m in grp.members if m is not w])
+    todo = []
+    for t in cand:
+        ent = getattr(t, "_e2e_layouts", None)
+        if ent is None or t.device != w.device or ent["wf"].device != t.device or ent["key"] == _layout_key(t):
             continue
-        live.append(r)
-        ent = t._e2e_layouts
-        key = (t.data_ptr(), t._version, WEIGHT_EPOCH[0])
-        if t.device != device or ent["key"] == key:
-            continue
-        Cout, Cin, KH, KW = t.shape
-        rows.append([t.data_ptr(), ent["wf"].data_ptr(), ent["wb"].data_ptr() if ent["wb"] is not None else 0,
-                     Cout, Cin, KH, KW, _ld(Cout), _ld(Cin), 0])
-        sig.append((t.data_ptr(), ent["wf"].data_ptr(), rows[-1][2]))
-        ent["key"] = key
-    _REGISTRY[:] = live
-    if not rows:
+        todo.append((t, ent, ent["wf"], ent["wb"]))
+    if not todo:
         return
-    sig = tuple(sig)
-    cached = _DESC.get(device)
-    if cached is None or cached[0] != sig:
-        cached = (sig, torch.tensor(rows, dtype=torch.int64).to(device))
-        _DESC[device] = cached
-    L.call("e2e_conv_weight_layouts_batched", L.ptr(cached[1]), len(rows), L.stream())
+    if len(todo) == 1:
+        t, ent, wf, wb = todo[0]
+        Cout, Cin, KH, KW = t.shape
+        L.call("e2e_conv_weight_layouts", L.ptr(t), Cout, Cin, KH, KW, L.ptr(wf), _ld(Cout), L.ptr(wb), _ld(Cin), L.stream())
+        ent["key"] = _layout_key(t)
+        return
+    rows = []
+    for t, ent, wf, wb in todo:
+        Cout, Cin, KH, KW = t.shape
+        rows.append([t.data_ptr(), wf.data_ptr(), wb.data_ptr() if wb is not None else 0, Cout, Cin, KH, KW, _ld(Cout), _ld(Cin), 0])
+    sig = tuple(tuple(r) for r in rows)
+    if grp._sig != sig:
+        grp._desc = torch.tensor(rows, dtype=torch.int64).to(w.device)
+        grp._sig = sig
+    L.call("e2e_conv_weight_layouts_batched", L.ptr(grp._desc), len(rows), L.stream())
+    for t, ent, _, _ in todo:
+        ent["key"] = _layout_key(t)
+    del todo
 
 
 def available():
@@ -320,24 +380,6 @@ def _ld(n):
     return (n + 3) // 4 * 4
 
 
-TUNING = [None]       # (tile_m, tile_n, ksplit) forced on the GEMMs of this MODULE path by tools / tests (gemm_tuning); the library itself is stateless
-
-
-class gemm_tuning:
-    """with gemm_tuning(tile_m, tile_n, ksplit): every conv2d forward / backward-data inside runs that decomposition (ksplit >= 1: K
-    slices, < 0: stream-K on -ksplit persistent workgroups of 64 x 64 tiles) through the *_tuned entry points."""
-
-    def __init__(self, tile_m, tile_n, ksplit):
-        self.t = (int(tile_m), int(tile_n), int(ksplit))
-
-    def __enter__(self):
-        self.prev, TUNING[0] = TUNING[0], self.t
-        return self
-
-    def __exit__(self, *exc):
-        TUNING[0] = self.prev
-
-
 def _gemm_workspace(n, dev):
     """A convolution GEMM workspace: its head (e2e_conv_workspace_flag_floats) holds the stream-K flags, zero outside a launch."""
     if not n:
@@ -355,7 +397,7 @@ def check_streamk(ws):
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src0, src1, weight, bias, scale, shift, residual, up, stride, pad, pad_mode, act, in_norm, wf, wb):
+    def forward(ctx, src0, src1, weight, bias, scale, shift, residual, up, stride, pad, pad_mode, act, in_norm, wf, wb, tune):
         ctx.params = (weight, bias)
         Cout, Cin, KH, KW = weight.shape
         src0 = _cl(L.dev(src0, "input"))
@@ -383,7 +425,6 @@ class _Conv2d(torch.autograd.Function):
             residual = _cl(L.dev(residual, "residual"))
         out = torch.empty(B, Cout, Ho, Wo, device=dev, dtype=torch.float32, memory_format=CL)
         isub, imul = in_norm if in_norm is not None else (0.0, 1.0)
-        tune = TUNING[0]
         if tune is not None:
             ws = _gemm_workspace(L.load().e2e_conv_tuned_workspace_floats(B * Ho * Wo, Cout), dev)
             L.call("e2e_conv2d_fwd_tuned", L.ptr(src0), L.ptr(src1), C1, up, L.ptr(wf), ldf, L.ptr(scale), L.ptr(sh), L.ptr(residual), L.ptr(out),
@@ -457,8 +498,8 @@ class _Conv2d(torch.autograd.Function):
             ws = torch.empty(L.load().e2e_conv2d_wgrad_workspace_floats(B, Ho, Wo, Cin, Cout, KH, KW, 1 if gb is not None else 0),
                              device=dev, dtype=torch.float32)
             st_w = st
-            if direct and OVERLAP[0]:
-                side = _side_stream(dev)
+            side = _overlap_stream(ctx.params[0]) if direct else None
+            if side is not None:
                 side.wait_stream(torch.cuda.current_stream(dev))          # dZ (and everything before it) is ready
                 for t in (dZ, src0, src1, ws):
                     if t is not None:
@@ -468,13 +509,16 @@ class _Conv2d(torch.autograd.Function):
                    Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, 1 if direct else 0, isub, imul, st_w)
             if direct:
                 gw = gb = None
-        return g0, g1, gw, gb, None, None, d_res, None, None, None, None, None, None, None, None
+        return g0, g1, gw, gb, None, None, d_res, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, pad_mode="zeros", act=None, bn_scale_shift=None, residual=None,
-           skip=None, upsample=1, in_norm=None):
+           skip=None, upsample=1, in_norm=None, tuning=None):
     """act( scale * conv(cat(upsample(x, upsample), skip)) + shift (+ residual) ).
-    bn_scale_shift: (scale, shift) per output channel (folded eval-mode BatchNorm; constants, no gradient)."""
+    bn_scale_shift: (scale, shift) per output channel (folded eval-mode BatchNorm; constants, no gradient).
+    tuning: None (the library's measured rule) or (tile_m, tile_n, ksplit) -- THIS call's forward and backward-data GEMMs run that
+    decomposition through the *_tuned entry points (ksplit >= 1: K slices, < 0: stream-K on -ksplit persistent workgroups of
+    64 x 64 tiles); tests and tools/gemm_tune.py use it, the library and this module keep no tuning state."""
     if pad_mode not in ("zeros", "reflect"):
         raise ValueError(f"pad_mode {pad_mode}")
     if tuple(weight.shape) == (1, 1, 1, 1):
@@ -495,4 +539,5 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, pad_mode="zeros", act=None
     want_bwd = torch.is_grad_enabled() and (x.requires_grad or (skip is not None and skip.requires_grad))
     wf, wb = _weight_layouts(weight, want_bwd)          # cached on the Parameter object across forwards
     return _Conv2d.apply(x, skip, weight, bias, scale, shift, residual, int(upsample), int(stride), int(padding),
-                         1 if pad_mode == "reflect" else 0, ACT[act], in_norm, wf, wb)
+                         1 if pad_mode == "reflect" else 0, ACT[act], in_norm, wf, wb,
+                         None if tuning is None else tuple(int(v) for v in tuning))

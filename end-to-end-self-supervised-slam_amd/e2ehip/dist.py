@@ -60,8 +60,7 @@ def broadcast_parameters_(flat, src=0):
         flat.data.copy_(h)
     else:
         dist.broadcast(flat.data, src=src)
-    from . import conv
-    conv.WEIGHT_EPOCH[0] += 1
+    flat.touched()
 
 
 def exchange_gradients_(flat, participating=True):

@@ -28,7 +28,7 @@ import ctypes
 import torch
 
 from . import _lib as L
-from .conv import ACT, WEIGHT_EPOCH, _ld
+from .conv import ACT, _ld, epoch_sum
 
 _f32 = torch.float32
 
@@ -310,11 +310,18 @@ class NetPlan:
             self._desc = torch.tensor([op.layout_row() for op in convs], dtype=torch.int64).to(self.dev)
             self._desc_key = key
         L.call("e2e_conv_weight_layouts_batched", L.ptr(self._desc), len(convs), st if st is not None else L.stream())
-        self._epoch = WEIGHT_EPOCH[0]
+        self.mark_layouts_current()
+
+    def _stamp(self):
+        ws = [op.weight for op in self.ops if isinstance(op, _Conv)]
+        return (tuple(w.data_ptr() for w in ws), tuple(w._version for w in ws), epoch_sum(ws))
+
+    def mark_layouts_current(self):
+        """The plan's GEMM layouts match the weights as they are now (a replayed graph refreshed them after its Adam launch)."""
+        self._epoch = self._stamp()
 
     def layouts_current(self):
-        convs = [op for op in self.ops if isinstance(op, _Conv)]
-        return self._desc is not None and self._desc_key == tuple(op.weight.data_ptr() for op in convs) and self._epoch == WEIGHT_EPOCH[0]
+        return self._desc is not None and getattr(self, "_epoch", None) == self._stamp()
 
     # -- streams -------------------------------------------------------------------------------------------------------
     def fork(self, st):
@@ -323,6 +330,7 @@ class NetPlan:
             return st
         if self._side is None:
             self._side = torch.cuda.Stream(self.dev)
+            self._record_side_stream_use()
         self._side.wait_stream(torch.cuda.current_stream(self.dev))
         self._forked = True
         return ctypes.c_void_p(self._side.cuda_stream)
@@ -331,6 +339,32 @@ class NetPlan:
         if self.overlap and self._side is not None and getattr(self, "_forked", False):
             torch.cuda.current_stream(self.dev).wait_stream(self._side)
             self._forked = False
+
+    def _record_side_stream_use(self):
+        """Every buffer a backward-weight chain touches on the side stream is marked as used there (once: the mark stays with the
+        block), so that the caching allocator does not hand the block to another stream's allocation, when the plan dies, before the
+        side stream's last launch on it has finished.  join() already orders each backward pass before whatever the current stream does
+        next; this covers the destruction of a plan whose last join was recorded on a different stream than the one that frees it."""
+        seen = set()
+        for op in self.ops:
+            ts = [op.out.t, op.out.g]
+            if isinstance(op, _Conv):
+                ts += [op.scale, op.ws_w, op.src0.t, op.src1.t if op.src1 is not None else None]
+                for p in (op.weight, op.bias):
+                    if p is not None:
+                        ts.append(_sink_of(p))
+            for t in ts:
+                if t is not None and t.is_cuda and t.untyped_storage().data_ptr() not in seen:
+                    seen.add(t.untyped_storage().data_ptr())
+                    t.record_stream(self._side)
+
+    def close(self):
+        """Deterministic end of the plan: both streams drained, nothing of it in flight; the buffers go back to the allocator when the
+        last reference dies, with no pending work on any stream."""
+        if self._side is not None:
+            self._side.synchronize()
+        torch.cuda.current_stream(self.dev).synchronize()
+        self.ops, self._sinks, self._desc = [], {}, None
 
     # -- the two passes ------------------------------------------------------------------------------------------------
     def forward(self, frames=None):

@@ -10,8 +10,6 @@ import torch
 from . import conv
 from ._lib import E2EError
 
-_BN_CACHE = {}
-
 
 def _require_device(x):
     if not x.is_cuda:
@@ -19,17 +17,19 @@ def _require_device(x):
 
 
 def _fold_bn(bn):
-    """eval-mode BatchNorm as per-channel (scale, shift); cached until any of its tensors changes."""
+    """eval-mode BatchNorm as per-channel (scale, shift); cached ON the BatchNorm's weight tensor until any of its tensors changes
+    (round 3 kept a module-level dict keyed by id(weight): an id -- and, through the caching allocator, the four data pointers -- of
+    a dead model's BatchNorm can be reissued to a new one, whose fold would then have been the dead model's)."""
     w, b, rm, rv, eps = bn
     key = (w.data_ptr(), b.data_ptr(), rm.data_ptr(), rv.data_ptr(), w._version, b._version, rm._version, rv._version, float(eps),
-           conv.WEIGHT_EPOCH[0] if (w.requires_grad or b.requires_grad) else -1)
-    hit = _BN_CACHE.get(id(w))
+           conv.epoch_of(w), conv.epoch_of(b))
+    hit = getattr(w, "_e2e_bnfold", None)
     if hit is None or hit[0] != key:
         with torch.no_grad():
             scale = (w / torch.sqrt(rv + eps)).contiguous()
             shift = (b - rm * scale).contiguous()
         hit = (key, scale, shift)
-        _BN_CACHE[id(w)] = hit
+        w._e2e_bnfold = hit
     return hit[1], hit[2]
 
 

@@ -373,9 +373,15 @@ class _Knn1(torch.autograd.Function):
     def backward(ctx, gd, _gi):
         a, b, idx = ctx.saved_tensors
         gd = gd.contiguous()
-        gp = torch.empty_like(a)
-        L.call("e2e_knn1_bwd", L.ptr(gd), L.ptr(a), L.ptr(b), L.ptr(idx), a.shape[0], L.ptr(gp), L.stream())
-        return gp, None, None
+        gp = gq = None
+        if ctx.needs_input_grad[0]:
+            gp = torch.empty_like(a)
+            L.call("e2e_knn1_bwd", L.ptr(gd), L.ptr(a), L.ptr(b), L.ptr(idx), a.shape[0], L.ptr(gp), L.stream())
+        if ctx.needs_input_grad[1]:          # the reference cloud is differentiable (ChamferDistance's reverse term): reproducible scatter
+            gq = torch.empty_like(b)
+            fx = torch.empty(3 * b.shape[0] + 1, device=b.device, dtype=torch.int64)
+            L.call("e2e_knn1_bwd_ref", L.ptr(gd), L.ptr(a), L.ptr(b), L.ptr(idx), a.shape[0], b.shape[0], L.ptr(fx), L.ptr(gq), L.stream())
+        return gp, gq, None
 
 
 class KnnIndex:
@@ -421,8 +427,8 @@ class _Knn1Indexed(torch.autograd.Function):
 
 def knn1(p1, p2, algorithm="auto"):
     """p2 may be a KnnIndex (prebuilt grid over the reference cloud).  algorithm: "auto" | "brute" | "grid" (identical results).  K=1 nearest neighbour of every row of p1 (P1,3) among p2 (P2,3): (squared dists (P1,), idx (P1,) int64).
-    Differentiable wrt p1 (d/dp1 = 2 g (p1 - p2[idx])); p2 is treated as data (the reference detaches it,
-    online_adaption.py:643)."""
+    Differentiable wrt p1 (d/dp1 = 2 g (p1 - p2[idx])) and -- plain tensors only, not a prebuilt index -- wrt p2 (the scatter of the
+    negative, as chamferdist's knn_points; the online path detaches p2, online_adaption.py:643)."""
     if isinstance(p2, KnnIndex) or getattr(p2, "resident", False):       # a prebuilt index (e2ehip.fusionmap.ResidentKnnIndex over the map)
         if p1.dim() != 2 or p1.shape[1] != 3 or p1.shape[0] == 0:
             raise ValueError(f"p1: expected non-empty (P,3), got {tuple(p1.shape)}")
@@ -432,8 +438,6 @@ def knn1(p1, p2, algorithm="auto"):
     for n, t in (("p1", p1), ("p2", p2)):
         if t.dim() != 2 or t.shape[1] != 3:
             raise ValueError(f"{n}: expected (P,3), got {tuple(t.shape)}")
-    if p2.requires_grad:
-        raise NotImplementedError("gradient wrt the reference cloud (p2) is not on the reference path; detach it")
     if p1.shape[0] == 0 or p2.shape[0] == 0:
         raise ValueError("knn1: empty point cloud")
     return _Knn1.apply(p1, p2, KNN_ALGORITHMS[algorithm])

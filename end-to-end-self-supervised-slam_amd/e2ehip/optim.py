@@ -29,14 +29,27 @@ class FlatParams:
             for p, o in zip(params, offs):
                 self.data[o:o + p.numel()].copy_(p.reshape(-1))
                 p.data = self.data[o:o + p.numel()].view_as(p)
-        from . import conv
-        conv.WEIGHT_EPOCH[0] += 1                      # parameters moved: cached GEMM layouts are stale
+        # state the convolution module path reads through the parameters (e2ehip.conv): a counter of raw-pointer rewrites of the
+        # parameters (their torch version counters do not move), and the direct-gradient switch + side stream of direct_weight_grads()
+        self.epoch = [1]
+        self.direct, self.overlap, self.side = False, False, None
         self.bind_grads()
 
     def bind_grads(self):
         for p, o in zip(self.params, self.offsets):
             p.grad = self.grad[o:o + p.numel()].view_as(p)
             p._e2e_grad_sink = p.grad              # conv backward may accumulate straight into it (conv.direct_weight_grads)
+            p._e2e_grad_owner = self
+            p._e2e_epoch = self.epoch
+
+    def touched(self):
+        """The parameters were rewritten through raw pointers (Adam kernel, broadcast): GEMM layouts cached on them are stale."""
+        self.epoch[0] += 1
+
+    def side_stream(self):
+        if self.side is None:
+            self.side = torch.cuda.Stream(self.data.device)
+        return self.side
 
     def zero_grad(self):
         self.grad.zero_()
@@ -60,7 +73,10 @@ class FusedAdam(torch.optim.Optimizer):
         # weight_decay / amsgrad: torch.optim.Adam's remaining defaults, carried (at their off values) so that a state dict written here
         # is a complete torch.optim.Adam state dict
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
-        self._all = params
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("FusedAdam steps ONE parameter group (one lr / betas / eps for the flat bucket)")
+        self._all = list(self.param_groups[0]["params"])
+        self._pending = None
         self.flat = None
         self.steps = 0              # host-side count of step() CALLS; the step that counts lives on the device (graph replays)
         self._sched = self._sched_key = self._counter = None
@@ -98,6 +114,7 @@ class FusedAdam(torch.optim.Optimizer):
                 p.grad.copy_(g)
         self.m = torch.zeros_like(self.flat.data)
         self.v = torch.zeros_like(self.flat.data)
+        self._apply_pending()
 
     def prebuild(self, params):
         """Fix the flat layout before the first backward (data-parallel runs: a rank may have to join a gradient exchange
@@ -111,6 +128,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.flat = FlatParams(act)
         self.m = torch.zeros_like(self.flat.data)
         self.v = torch.zeros_like(self.flat.data)
+        self._apply_pending()
 
     # ---- torch.optim.Adam-compatible state (train_depth.py:849-863 resumes from `<optimizer>.pth`) --------------------------------
     def state_dict(self):
@@ -125,7 +143,9 @@ class FusedAdam(torch.optim.Optimizer):
             start += len(g["params"])
             groups.append(d)
         state = {}
-        if self.flat is not None:
+        if self.flat is None and getattr(self, "_pending", None):
+            state = {i: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in self._pending.items()}     # loaded, not applied yet
+        elif self.flat is not None and self.steps_done() > 0:                  # like torch: no state before the first step
             t = float(self.steps_done())
             idx = {id(p): i for i, p in enumerate(self._all)}
             for p, o in zip(self.flat.params, self.flat.offsets):
@@ -134,41 +154,59 @@ class FusedAdam(torch.optim.Optimizer):
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, state_dict):
-        """Counterpart of torch.optim.Optimizer.load_state_dict for the flat layout: hyper-parameters of the first group, moments and
-        step count.  The flat bucket is laid out over the parameters that carry state (plus, when it exists already, whatever it holds);
-        Adam here keeps ONE step counter for the bucket, torch one per parameter -- they are equal in any file an Adam run wrote."""
+        """Counterpart of torch.optim.Optimizer.load_state_dict for the flat layout: hyper-parameters, moments and step count.
+        WHICH parameters the flat bucket holds is decided where it always is -- at prebuild() (the caller names the parameters that
+        take part) or at the first step() (those with a gradient) -- never by the file: loaded before that, the state waits and is
+        applied when the bucket exists.  Adam here keeps ONE step counter for the bucket, torch one per parameter; they are equal in
+        any file an Adam run over the same parameters wrote.  A bucket parameter WITHOUT state in a file whose others have stepped
+        (torch would start it at step 0 with its own bias correction) cannot be represented and raises instead of being silently
+        mis-stepped or -- round 3 -- silently left out of the bucket and never updated."""
         groups = state_dict["param_groups"]
-        if len(groups) != len(self.param_groups) or sum(len(g["params"]) for g in groups) != len(self._all):
-            raise ValueError("loaded state dict has a different number of parameter groups / parameters")
-        for g, src in zip(self.param_groups, groups):
-            if src.get("weight_decay", 0) or src.get("amsgrad", False) or src.get("maximize", False):
-                raise NotImplementedError("FusedAdam: weight_decay / amsgrad / maximize are not on the reference's path (training_utils.py:23-25)")
-            g.update({k: v for k, v in src.items() if k in ("lr", "betas", "eps")})
+        if len(groups) != 1 or len(self.param_groups) != 1:
+            raise NotImplementedError("FusedAdam steps ONE parameter group (one lr / betas / eps for the flat bucket)")
+        if len(groups[0]["params"]) != len(self._all):
+            raise ValueError("loaded state dict has a different number of parameters")
+        src = groups[0]
+        if src.get("weight_decay", 0) or src.get("amsgrad", False) or src.get("maximize", False):
+            raise NotImplementedError("FusedAdam: weight_decay / amsgrad / maximize are not on the reference's path (training_utils.py:23-25)")
+        self.param_groups[0].update({k: v for k, v in src.items() if k in ("lr", "betas", "eps")})
+        self._sched_key = None                              # lr / betas may have changed: rebuild the bias-correction table at the next step
         state = {int(k): v for k, v in state_dict["state"].items()}
+        for i, st in state.items():
+            if not 0 <= i < len(self._all):
+                raise ValueError(f"state for parameter index {i}: the optimiser has {len(self._all)} parameters")
+            if tuple(st["exp_avg"].shape) != tuple(self._all[i].shape):
+                raise ValueError(f"parameter {i}: state of shape {tuple(st['exp_avg'].shape)} for a parameter of shape {tuple(self._all[i].shape)}")
+        self._pending = state or None
+        if self.flat is not None:
+            self._apply_pending()
+
+    def _apply_pending(self):
+        state, self._pending = getattr(self, "_pending", None), None
         if not state:
             return
-        have = [self._all[i] for i in sorted(state) if self._all[i].requires_grad]
-        if self.flat is None:
-            self.prebuild(have)
-        offs = {id(p): o for p, o in zip(self.flat.params, self.flat.offsets)}
-        steps = set()
-        with torch.no_grad():
-            for i, st in state.items():
-                p = self._all[i]
-                if id(p) not in offs:
-                    raise ValueError(f"parameter {i} carries optimiser state but is not part of the flat bucket")
-                o, n = offs[id(p)], p.numel()
-                if tuple(st["exp_avg"].shape) != tuple(p.shape):
-                    raise ValueError(f"parameter {i}: state of shape {tuple(st['exp_avg'].shape)} for a parameter of shape {tuple(p.shape)}")
-                self.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
-                self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
-                steps.add(int(float(st["step"])))
+        idx = {id(p): i for i, p in enumerate(self._all)}
+        offs = {idx[id(p)]: (o, p.numel()) for p, o in zip(self.flat.params, self.flat.offsets)}
+        steps = {int(float(st["step"])) for st in state.values()}
         if len(steps) != 1:
             raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused optimiser keeps one")
+        t = steps.pop()
+        missing = sorted(i for i in offs if i not in state)
+        if missing and t != 0:
+            raise ValueError(f"parameters {missing} are trained here but carry no state in the loaded file, whose other parameters are at "
+                             f"step {t}: torch.optim.Adam would run them on their own step count, the fused optimiser keeps one")
+        extra = sorted(i for i in state if i not in offs and self._all[i].requires_grad)
+        if extra:
+            raise ValueError(f"parameters {extra} carry optimiser state but are not part of the flat bucket (not among the parameters "
+                             "named to prebuild() / without a gradient at the first step)")
+        with torch.no_grad():
+            for i, st in state.items():
+                if i in offs:
+                    o, n = offs[i]
+                    self.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                    self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
         self._resident_state()
-        self._counter.fill_(steps.pop() + 1)
-        self._sched_key = None                              # lr / betas may have changed: rebuild the bias-correction table at the next step
-        self._resident_state()
+        self._counter.fill_(t + 1)
 
     def zero_grad(self, set_to_none=True):
         if self.flat is None:
@@ -183,8 +221,7 @@ class FusedAdam(torch.optim.Optimizer):
             self._build()
         g = self.param_groups[0]
         self.steps += 1
-        from . import conv
-        conv.WEIGHT_EPOCH[0] += 1                      # the kernel rewrites the weights behind torch's version counters
+        self.flat.touched()                            # the kernel rewrites the weights behind torch's version counters
         # the bucket holds the SUM over the data-parallel ranks and its tail the number of contributors (1 on a single GPU);
         # step count and bias corrections are device-resident, so this launch can be captured into a hipGraph and replayed
         sched, counter = self._resident_state()

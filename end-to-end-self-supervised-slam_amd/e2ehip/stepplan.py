@@ -17,7 +17,6 @@ bench.py can time the individual launches.  No host synchronisation anywhere in 
 import torch
 
 from . import _lib as L
-from . import conv as e2e_conv
 from . import dist as edist
 from .fused import LossGradPlan
 from .netplan import NetPlan
@@ -66,6 +65,11 @@ class RefineStepPlan:
         self.g3 = torch.zeros(1, 1, H, W, **f)
         self.ws_aux = torch.empty(lib.e2e_aux_workspace_floats(), **f)
         self._graphs, self._gstream = {}, None
+        # the uint32 inside ws_scale that names the median ELEMENT of the predictions -- where the ratio's gradient lands
+        # (online_adaption.py:295-298; torch.median's `indices`).  median_index_override (a device int32[1], tests): written there between
+        # the forward and the backward of a step, to make the choice among near-tied elements the oracle's instead of this kernel's
+        self._median_slot = self.ws_scale.view(torch.int32)[lib.e2e_median_index_offset_bytes() // 4: lib.e2e_median_index_offset_bytes() // 4 + 1]
+        self.median_index_override = None
         self.net.refresh_layouts()
 
     # ---- per keyframe -----------------------------------------------------------------------------------------------------
@@ -87,6 +91,8 @@ class RefineStepPlan:
 
     # ---- graph plumbing ---------------------------------------------------------------------------------------------------
     def _run(self, key, fn):
+        if getattr(self, "_closed", False):
+            raise RuntimeError("RefineStepPlan used after close()")
         if not self.use_graphs or L.PROFILE_HOOK[0] is not None:
             return fn()
         g = self._graphs.get(key)
@@ -156,6 +162,8 @@ class RefineStepPlan:
         self._run("fwd", self._forward)
         if first_step and self.reg:
             self.init.copy_(self.delta)
+        if self.median_index_override is not None:
+            self._median_slot.copy_(self.median_index_override)
         # the 3-D loss against a RESIDENT index (e2ehip.fusionmap: one buffer per run, map size on the device) has constant launch
         # arguments and rides in the backward graph; any other index object is queried eagerly here
         cap_idx, ikey = None, None
@@ -176,8 +184,13 @@ class RefineStepPlan:
             self._run("bwd_early", self.net.backward_early_layers)
             edist.exchange_gradients_early_(self.opt.flat, self._split, handle, True)
             self._run("adam", self._adam)
-        e2e_conv.WEIGHT_EPOCH[0] += 1                               # parameters changed behind torch's version counters (module-path caches)
-        self.net._epoch = e2e_conv.WEIGHT_EPOCH[0]
+        self._parameters_stepped()
+
+    def _parameters_stepped(self):
+        """A (possibly replayed) Adam launch rewrote the parameters behind torch's version counters: module-path layout caches of
+        these parameters are stale (FlatParams.touched), the plan's own layouts were refreshed inside the same graph."""
+        self.opt.flat.touched()
+        self.net.mark_layouts_current()
 
     def idle_step(self):
         """A step of a rank without a keyframe in this round (data-parallel runs): zero bucket in, averaged update out."""
@@ -186,8 +199,7 @@ class RefineStepPlan:
         handle = edist.exchange_gradients_late_(self.opt.flat, self._split, False)      # the same two collectives as a participating rank
         edist.exchange_gradients_early_(self.opt.flat, self._split, handle, False)
         self._run("adam", self._adam)
-        e2e_conv.WEIGHT_EPOCH[0] += 1
-        self.net._epoch = e2e_conv.WEIGHT_EPOCH[0]
+        self._parameters_stepped()
 
     def predict_depths(self):
         """Median-scaled depths of the loaded pair with the current network (the map update's forward pass,
@@ -208,6 +220,21 @@ class RefineStepPlan:
             fmap.knn_index(self.N)                                  # rebuilt in place from the device-resident point count
         self._run(("map", bool(first), id(fmap)), fn)
         fmap.mark_updated_on_device(index_current=True)
+
+    def close(self):
+        """Deterministic end of the plan (tests build many; a product process builds one): wait for everything it launched -- current
+        stream, capture stream, backward-weight side stream --, destroy the captured graphs and with them their private memory pools,
+        drop the network plan's buffers.  Using the plan afterwards raises."""
+        torch.cuda.current_stream(self.dev).synchronize()
+        if self._gstream is not None:
+            self._gstream.synchronize()
+        self._graphs.clear()
+        self.net.close()
+        self._closed = True
+
+    def median_index(self):
+        """Flat index (into the stacked (2,1,H,W) predictions) of the element the last forward chose as the median (device int32[1])."""
+        return self._median_slot
 
     def losses(self):
         """(photometric mean, regulariser sum of means, 3-D loss mean) of the last step as device tensors (no sync)."""

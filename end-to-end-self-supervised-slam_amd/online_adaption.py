@@ -181,6 +181,20 @@ class SLAM:
             self.gathered_map = edist.gather_maps(*self.map.live())
         return self.map
 
+    def close(self):
+        """End of this SLAM object's GPU work: the step plan's streams joined and its graphs destroyed (RefineStepPlan.close), the
+        device idle.  main() may not be called again afterwards; map and network stay readable."""
+        if self.step_plan is not None:
+            self.step_plan.close()
+            self.step_plan = None
+        torch.cuda.synchronize(self.device)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def idle_round(self):
         """A keyframe round of another rank: contribute a zero bucket to each of its gradient exchanges and apply the
         same averaged update, so that the shared depth network stays identical on every rank."""
@@ -333,7 +347,7 @@ class SLAM:
                 l3 = self.compute_3d_loss(d_tgt, K, poses[:, 1], T)
                 roots.append(l3 * a.LOSS.three3d_loss_weight)
                 grads.append(None)
-            with e2e_conv.direct_weight_grads(overlap=self.overlap_wgrad_autograd):     # weight gradients accumulate straight into FusedAdam's flat bucket
+            with e2e_conv.direct_weight_grads(self.optimizer, overlap=self.overlap_wgrad_autograd):     # weight gradients accumulate straight into FusedAdam's flat bucket
                 torch.autograd.backward(roots, grads)
             self._exchange_gradients()
             self.optimizer.step()

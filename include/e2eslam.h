@@ -269,6 +269,13 @@ int e2e_knn1_fwd(const float* p1, int64_t n1, const float* p2, int64_t n2, float
 /* g_p1 = 2 g_dists (p1 - p2[idx]) */
 int e2e_knn1_bwd(const float* g_dists, const float* p1, const float* p2, const long long* idx,
                  int64_t n1, float* g_p1, void* stream);
+/* The other half of chamferdist's knn_points backward (un-vendored, SURVEY.md Appendix A: "d p2 = scatter of the negative"):
+ *   g_p2[idx[i]] += -2 g_dists[i] (p1[i] - p2[idx[i]])        (n2,3)
+ * reached by ChamferDistance(..., bidirectional=True) at train_depth.py:690-692, whose reverse term searches the
+ * differentiable cloud.  Collisions are summed as 2^-48 fixed-point integers (order independent, bitwise reproducible);
+ * scratch_fixed: 3*n2+1 int64, zeroed here.  A non-finite / >= 4096 contribution turns the whole result into NaN. */
+int e2e_knn1_bwd_ref(const float* g_dists, const float* p1, const float* p2, const long long* idx,
+                     int64_t n1, int64_t n2, long long* scratch_fixed, float* g_p2, void* stream);
 
 /* Persistent index over one reference set: build once, query many times (ICP iterations, the
  * refinement steps of one keyframe all search the same map).  `index`: caller-owned buffer of
@@ -308,6 +315,11 @@ int e2e_knn1_index_query_dev_image_warm(const float* p1, int64_t n1, int row_len
  * radix select; *value_out (device).  workspace: e2e_median_workspace_bytes() bytes; afterwards it
  * also holds the smallest index whose value equals the median (used by the scale chain's autograd). */
 int64_t e2e_median_workspace_bytes(void);
+/* Byte offset, inside the workspace, of the uint32 that names that element: the second result of torch.median(x, 0)
+ * (`indices`), i.e. the element autograd routes the ratio's gradient to (online_adaption.py:295-298).  A caller may read
+ * it after e2e_median_lower / e2e_depth_scale_fwd, and may overwrite it before e2e_depth_scale_bwd to name another
+ * element of equal value (torch returns "one index" among ties; this library the smallest). */
+int64_t e2e_median_index_offset_bytes(void);
 int e2e_median_lower(const float* x, int64_t n, float* value_out, void* workspace, void* stream);
 
 /* online_adaption.py:282,292-298 for the n = F*H*W elements of the stacked disparities:

@@ -65,3 +65,27 @@ def knn_points_loss(gt_points, noisy_points):
     q = noisy_points[0] - gt_points[0][idx]
     d = (q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1]) + q[:, 2] * q[:, 2]
     return d.mean(), idx.unsqueeze(0)
+
+
+def chamfer_distance(source, target, bidirectional=False, reverse=False, reduction="mean"):
+    """chamferdist.ChamferDistance.forward as SURVEY.md Appendix A restates it (un-vendored, PARITY UNPINNED): the `reduction` of the
+    squared nearest-neighbour distances source -> target (+ target -> source when bidirectional, only that when reverse); call site
+    train_depth.py:690-692.  source (1,P,3), target (1,M,3).  Gradients reach BOTH clouds (knn_points' backward: d p1 = 2 g (p1 - p2[idx]),
+    d p2 = the scatter of the negative), which autograd derives here from the gathered difference."""
+    red = {"mean": torch.mean, "sum": torch.sum}[reduction]
+
+    def one_way(a, b):
+        _, idx = knn1(a[0], b[0])
+        q = a[0] - b[0][idx]
+        return red((q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1]) + q[:, 2] * q[:, 2])
+    fwd = one_way(source, target)
+    if bidirectional:
+        return fwd + one_way(target, source)
+    return one_way(target, source) if reverse else fwd
+
+
+def color_points_loss(gt_color, noisy_color, indexes):
+    """loss/losses.py:65-82: mean |noisy colour - colour of its nearest ground-truth point|; (1,M,3), (1,P,3), idx (1,P)."""
+    if gt_color.shape[2] != noisy_color.shape[2]:
+        raise ValueError("Number of axes is not the same in both pointclouds")
+    return torch.mean(torch.abs(noisy_color[0] - gt_color[0, indexes[0].long()]))

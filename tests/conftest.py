@@ -38,20 +38,3 @@ def load_golden(name):
 @pytest.fixture
 def golden():
     return load_golden
-
-
-@pytest.fixture(autouse=True)
-def _no_async_work_leaks_between_tests(request):
-    """GPU tests: nothing of a test is still in flight, and nothing of it still owns device memory, when the next one starts.  A driver test
-    leaves gigabytes of plan / map / graph state behind whose destruction is up to the garbage collector; a later test then allocated
-    from blocks whose previous owner had launches pending on another stream of the same process (graph-capture stream, backward-weight
-    side stream) -- order-dependent one-in-three failures of unrelated module-path tests in round 3.  Product objects (one SLAM per
-    process) never see this; the tests should not either."""
-    yield
-    mode = os.environ.get("E2E_TEST_TEARDOWN", "sync+gc")      # diagnostics: "none" (round-3 behaviour before this fixture), "sync", "sync+gc"
-    if "gpu" in request.keywords and torch.cuda.is_available() and mode != "none":
-        import gc
-        torch.cuda.synchronize()
-        if mode == "sync+gc":
-            gc.collect()
-            torch.cuda.synchronize()

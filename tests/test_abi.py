@@ -45,3 +45,32 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
                     bad.append(os.path.join(dp, f))
     assert not bad, f"product code imports the oracle: {bad}"
+
+
+def test_convolution_module_path_keeps_no_process_wide_state():
+    """the module path of the convolutions (e2ehip.conv / e2ehip.nn_ops) kept a process-global registry of every
+    weight ever built, refreshed from raw device pointers.  State now hangs on the objects it describes (weight, model, optimiser):
+    the modules own no mutable container besides the constant ACT table, and no module-level switch."""
+    from e2ehip import conv, nn_ops
+    for mod in (conv, nn_ops):
+        for name, val in vars(mod).items():
+            if name.startswith("__") or name == "ACT":
+                continue
+            assert not isinstance(val, (list, dict, set)), f"{mod.__name__}.{name} is module-level mutable state"
+
+
+def test_layout_group_is_per_model_and_holds_its_members():
+    """The weights refreshed together are those of ONE model, strongly referenced by the group the model owns."""
+    import gc
+    import weakref
+    from depth_estimation.networks import DispResNet_Indoor
+    a, b = DispResNet_Indoor(18, False), DispResNet_Indoor(18, False)
+    ga, gb = a._layout_group, b._layout_group
+    assert ga is not gb and len(ga.members) == len(gb.members) == 30
+    assert all(w._e2e_group is ga for w in ga.members) and not ({id(w) for w in ga.members} & {id(w) for w in gb.members})
+    # encoder / decoder sub-groups were superseded by the model's group
+    assert not a.encoder._layout_group.members and not a.decoder._layout_group.members
+    ref = weakref.ref(a.encoder.encoder.conv1.weight)
+    del a, ga
+    gc.collect()
+    assert ref() is None, "a dead model's weights must not be kept alive by anything process-wide"

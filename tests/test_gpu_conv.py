@@ -129,7 +129,7 @@ def test_disparity_head(H, W, act):
 @pytest.mark.parametrize("tile", [(64, 64), (128, 64), (128, 128), (128, 32), (32, 128), (32, 64), (64, 32), (32, 32)], ids=lambda t: f"{t[0]}x{t[1]}")
 @pytest.mark.parametrize("ksplit", [1, 3])
 def test_every_gemm_decomposition(tile, ksplit):
-    """Each workgroup-tile family and split-K forced in turn (per call: conv.gemm_tuning -> e2e_conv2d_*_tuned) on one layer that all
+    """Each workgroup-tile family and split-K forced in turn (per call: conv2d(..., tuning=) -> e2e_conv2d_*_tuned) on one layer that all
     of them fit: forward, backward-data and -- through the same gather -- a stride-2 parity-class backward."""
     from e2ehip import conv
     g = torch.Generator().manual_seed(tile[0] * 7 + tile[1] + ksplit)
@@ -138,11 +138,10 @@ def test_every_gemm_decomposition(tile, ksplit):
         x = rnd(2, Cin, H, W).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
         w = (rnd(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5).to(DEV).requires_grad_(True)
         scale, shift = (rnd(Cout).abs() + 0.5).to(DEV), rnd(Cout).to(DEV)
-        with conv.gemm_tuning(tile[0], tile[1], ksplit):
-            y = conv.conv2d(x, w, None, s, 1, "zeros", "relu", (scale, shift))
-            yr = _ref(x, None, w, None, scale, shift, None, 1, s, 1, "zeros", "relu", None)
-            gy = _mask_kinks(rnd(*y.shape).to(DEV), yr, "relu")
-            gx, gw = torch.autograd.grad(y, [x, w], gy)
+        y = conv.conv2d(x, w, None, s, 1, "zeros", "relu", (scale, shift), tuning=(tile[0], tile[1], ksplit))
+        yr = _ref(x, None, w, None, scale, shift, None, 1, s, 1, "zeros", "relu", None)
+        gy = _mask_kinks(rnd(*y.shape).to(DEV), yr, "relu")
+        gx, gw = torch.autograd.grad(y, [x, w], gy)
         gxr, gwr = torch.autograd.grad(yr, [x, w], gy.double())
         for a, b, name in ((y, yr, "y"), (gx, gxr, "dx"), (gw, gwr, "dw")):
             e = ((a.double() - b).abs().max() / (b.abs().max() + 1e-30)).item()
@@ -169,12 +168,11 @@ def test_streamk_decomposition(G):
         res = rnd(2, Cout, H, W).to(DEV).contiguous(memory_format=torch.channels_last) if (pm == "zeros" and act) else None
         outs = []
         for rep in range(2):
-            with conv.gemm_tuning(64, 64, -G):
-                y = conv.conv2d(x, w, bias, 1, 1, pm, act, bn, res, skip, up)
-                ins = [x] + ([skip] if Cs else [])
-                yr = _ref(x, skip, w, bias, bn[0] if bn else None, bn[1] if bn else None, res, up, 1, 1, pm, act, None)
-                gy = _mask_kinks(torch.randn(*y.shape, generator=torch.Generator().manual_seed(5)).to(DEV), yr, act)
-                gs = torch.autograd.grad(y, ins, gy)
+            y = conv.conv2d(x, w, bias, 1, 1, pm, act, bn, res, skip, up, tuning=(64, 64, -G))
+            ins = [x] + ([skip] if Cs else [])
+            yr = _ref(x, skip, w, bias, bn[0] if bn else None, bn[1] if bn else None, res, up, 1, 1, pm, act, None)
+            gy = _mask_kinks(torch.randn(*y.shape, generator=torch.Generator().manual_seed(5)).to(DEV), yr, act)
+            gs = torch.autograd.grad(y, ins, gy)
             outs.append((y.detach().clone(), [t.clone() for t in gs]))
         assert torch.equal(outs[0][0], outs[1][0]) and all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
         gr = torch.autograd.grad(yr, ins, gy.double())

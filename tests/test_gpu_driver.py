@@ -37,7 +37,8 @@ def test_first_pair_matches_reference_trajectory(golden):
 @pytest.mark.parametrize("H,W", [(64, 96), (480, 640)], ids=["64x96", "480x640"])
 def test_every_step_of_two_keyframes_vs_oracle_teacher_forced(H, W):
     """Both keyframe pairs of a 3-frame sequence (the second one with the 3-D nearest-neighbour loss against the fused map), every
-    refinement step against the oracle's same step: loss terms, median ratio, metrics at 1e-4 and the parameters after the step.
+    refinement step against the oracle's same step: loss terms, median ratio, metrics at 1e-4, d loss / d depth, ALL 48 parameter
+    gradients in every step, and the parameters after the step.
 
     TEACHER FORCED: before each GPU step the network weights, Adam's moments / step count and (before the second pair) the map are
     set to the oracle's state at that point.  Free-running trajectories of two correct fp32 implementations decouple after 2-3
@@ -116,9 +117,10 @@ def test_every_step_of_two_keyframes_vs_oracle_teacher_forced(H, W):
             index = slam.map.knn_index(H * W)
         for k in range(3):
             load(snaps[step])
+            r = recs[step]
+            sp.median_index_override = torch.tensor([r["median_index"]], dtype=torch.int32, device="cuda")
             sp.step(k == 0, index)
             lp, lr, l3 = (float(v) for v in sp.losses())
-            r = recs[step]
             np.testing.assert_allclose(lp, r["photometric"], rtol=1e-4)
             np.testing.assert_allclose(lr, r["reg"], rtol=1e-4, atol=1e-9)
             np.testing.assert_allclose(float(sp.ratio), r["ratio"], rtol=1e-4)
@@ -144,18 +146,21 @@ def test_every_step_of_two_keyframes_vs_oracle_teacher_forced(H, W):
                 if n_out > max(4, 1e-3 * H * W) or rel2 > 5e-4:
                     failures.append(("g_depth", step, f, n_out, rel2))
             # parameter gradients, recovered from Adam's first moment (m' = b1 m + (1 - b1) g with m loaded from the oracle): every tensor
-            # within GRAD_TOL of its largest element, the bound of the network-gradient tests -- here through the whole loss chain.
-            # They are compared when both sides picked the SAME element as the median of the predictions (docstring): always at 64x96
-            # (the x40 head makes it unique); among 614 400 values the neighbours of the median are ~1e-6 apart, closer than two fp32
-            # evaluations of a depth agree, so at 480x640 the element may legitimately differ (measured: it agreed in 1 step of 6, and
-            # where it did not the parameter gradients of the two sides differed by 0.9 - 2.1 x the tensor's largest element: that one
-            # element carries most of the gradient) -- then only the one-update bound holds.  At 480x640 the bound is 1e-3: the
-            # kink pixels above feed the parameter gradients (measured 3e-4).
-            # (the kernel puts the term on the SMALLEST index holding the median value -- k_median_final; torch returns "one index of the
-            # median", so with tied values the two may still differ: the criterion is the element, not the value)
+            # within GRAD_TOL of its largest element, the bound of the network-gradient tests -- here through the whole loss chain, in
+            # EVERY step.  The reference keeps the median ratio inside the graph (online_adaption.py:295-298): its backward puts a sum over
+            # all pixels on the ONE element torch.median names, and that element carries most of the parameter gradient.  Among 614 400
+            # values the neighbours of the median are ~1e-6 apart, closer than two fp32 evaluations of a depth agree, so WHICH element
+            # it is differs between two correct evaluations (round 3 compared gradients only where it happened to agree: 1 step of 6).
+            # The choice is taken out of the comparison instead: the plan's median_index_override names the oracle's element
+            # (torch.median's `indices`) as the one the gradient lands on, after checking that on the GPU too its value is the
+            # median to within fp32 rounding of a depth; the median VALUE, the ratio and every loss term stay the GPU's own.
+            # At 480x640 the bound is 1e-3: the kink pixels above feed the parameter gradients (measured 3e-4).
             md_at = (sp.delta.reshape(-1) == sp.md).nonzero().reshape(-1).tolist()
             same_median = len(md_at) > 0 and min(md_at) == r["median_index"]
             assert same_median or (H, W) != (64, 96), (step, r["median_index"], sorted(md_at)[:4])
+            named = float(sp.delta.reshape(-1)[r["median_index"]])
+            assert abs(named - float(sp.md)) <= 1e-5 * abs(float(sp.md)), (step, named, float(sp.md))
+            assert int(sp.median_index()) == r["median_index"]
             # parameters after the step: Adam's update is lr * m^ / (sqrt(v^) + eps), sign-like in the first steps; where |g| is not far
             # above eps = 1e-8, or far below the tensor's largest gradient (relative error of g up to GRAD_TOL * max / |g|), the update
             # amplifies rounding-level differences of g to a sizeable part of lr.  So: NO element further than one update apart
@@ -175,11 +180,12 @@ def test_every_step_of_two_keyframes_vs_oracle_teacher_forced(H, W):
                 tot += int(well.sum())
                 worst = max(worst, float(d.max()))
             agreed.append((same_median, gworst, worst, bad / tot))
-            if worst > 2.2e-5 or (same_median and (gworst[0] > (GRAD_TOL if (H, W) == (64, 96) else 1e-3) or bad / tot >= 2e-3)):
+            if worst > 2.2e-5 or gworst[0] > (GRAD_TOL if (H, W) == (64, 96) else 1e-3) or bad / tot >= 2e-3:
                 failures.append(("parameters", step, same_median, gworst, worst, bad / tot))
             step += 1
         if pair == 0:                                   # the first keyframe's map update from the same weights (index tables: test_gpu_pointfusion_knn)
             load(snaps[3])
+            sp.median_index_override = None
             depth = sp.predict_depths()
             slam.first_iter = True
             slam._update_map(slam.colors[0, 0], slam.colors[0, 1], depth, slam.poses[0, 0], slam.poses[0, 1])
@@ -190,10 +196,64 @@ def test_every_step_of_two_keyframes_vs_oracle_teacher_forced(H, W):
             pa, pb = slam.map.live()[0][: H * W].cpu(), map_pair2["points"][: H * W]
             off = ((pa - pb).abs() > 1e-5 + 1e-4 * pb.abs()).any(1)
             assert int(off.sum()) <= 1e-5 * H * W, int(off.sum())
-    print(f"[teacher forced {H}x{W}] per step (median element agreed, worst gradient error / tensor, worst parameter difference, fraction of "
+    print(f"[teacher forced {H}x{W}] per step (GPU's own median element == the oracle's, worst gradient error / tensor, worst parameter difference, fraction of "
           f"well-conditioned elements beyond 3e-7): {agreed}")
     print(f"[teacher forced {H}x{W}] d loss / d depth (step, frame, pixels beyond 1e-4 of max, relative L2 error over the others): {gstats}")
     assert not failures, failures
+
+
+@pytest.mark.parametrize("H,W", [(64, 96), (480, 640)], ids=["64x96", "480x640"])
+def test_default_head_first_step_vs_oracle(H, W):
+    """Every other driver-level comparison scales the disparity head by 40 (a unique median, a well-conditioned loop).  This is the
+    network as the reference initialises it (head x 1: a nearly flat disparity, thousands of near-tied candidates for the median): ONE
+    teacher-forced step from the initial state -- loss terms, ratio, d loss / d depth of both frames and all 48 parameter gradients
+    (Adam's first moment after the first step is 0.1 g), the median element named by the oracle (see the test above)."""
+    from e2ehip.synthetic import make_sequence
+    from online_adaption import SLAM
+    seq = make_sequence(2, H, W, seed=9)
+    sd = depthnet.random_state_dict(0)
+    colors, gt, K, poses = seq
+    ocfg = refine.Config()
+    ocfg.refinement_steps = 1
+    ora = refine.Refiner(sd, ocfg)
+    grads = {}
+    orig = ora.opt.step
+
+    def keep_grads(*a, **k):
+        grads.update({kk: ora.sd[kk].grad.detach().clone() for kk in ora.train_keys})
+        return orig(*a, **k)
+    ora.opt.step = keep_grads
+    r = ora.refine_pair(colors, gt, poses, K, update_map=False)[0]
+    cfg = _cfg(H, W, 2)
+    cfg.DEBUG.print_metrics = False
+    slam = SLAM(cfg, sequence=seq, state_dict=sd)
+    slam.set_refinement_mode()
+    sp = slam._step_plan()
+    slam._load_pair(sp, 0, 1)
+    sp.median_index_override = torch.tensor([r["median_index"]], dtype=torch.int32, device="cuda")
+    sp.step(True, None)
+    lp, lr, _ = (float(v) for v in sp.losses())
+    np.testing.assert_allclose(lp, r["photometric"], rtol=1e-4)
+    np.testing.assert_allclose(lr, r["reg"], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(float(sp.ratio), r["ratio"], rtol=1e-4)
+    named = float(sp.delta.reshape(-1)[r["median_index"]])
+    assert abs(named - float(sp.md)) <= 1e-5 * abs(float(sp.md))
+    for f in range(2):
+        ga, gb = sp.g_depth[f, 0].cpu(), r["g_depth"][f][0, 0]
+        out = (ga - gb).abs() > 1e-4 * float(gb.abs().max())
+        assert int(out.sum()) <= max(4, 1e-3 * H * W), (f, int(out.sum()))
+        assert float(((ga - gb) * ~out).norm()) <= 5e-4 * float(gb.norm()) + 1e-30
+    params, opt = dict(slam.models["depth"].named_parameters()), slam.optimizer
+    offs = {id(p): o for p, o in zip(opt.flat.params, opt.flat.offsets)}
+    worst = (0.0, "")
+    for k in ora.train_keys:
+        p = params[k]
+        g_gpu = opt.m[offs[id(p)]:offs[id(p)] + p.numel()].view_as(p).cpu() / 0.1
+        err = float((g_gpu - grads[k]).abs().max()) / max(float(grads[k].abs().max()), 1e-30)
+        worst = max(worst, (err, k))
+    print(f"[default head {H}x{W}] worst parameter-gradient error / tensor max: {worst}")
+    assert worst[0] <= (GRAD_TOL if (H, W) == (64, 96) else 1e-3), worst
+    slam.close()
 
 
 def _run_two_keyframes(mode):
@@ -232,13 +292,14 @@ def test_launch_plan_equals_autograd_path_and_graph_replay_is_exact():
             torch.testing.assert_close(sd_g[k], sd_a[k], rtol=0, atol=2.5e-5, msg=k)     # <= 2 Adam steps of lr 1e-5 apart where a gradient sign is at noise level
 
 
-def test_tum_shaped_sequence_vs_oracle_first_keyframe():
-    """BASELINE configs[3] in small: TUM intrinsics (fx = fy = 525, positive fy), 10 % zero-depth holes in the ground truth,
+@pytest.mark.parametrize("H,W", [(64, 96), (480, 640)], ids=["64x96", "480x640"])
+def test_tum_shaped_sequence_vs_oracle_first_keyframe(H, W):
+    """BASELINE configs[3], in small and at its own 480x640: TUM intrinsics (fx = fy = 525, positive fy), 10 % zero-depth holes in the ground truth,
     DATA.name TUM (the holes are masked in depth_metrics only, losses.py:167-169; the median of the ground truth includes them,
     online_adaption.py:295), keyframe threshold 0.12: 3 refinement steps of the first keyframe against the oracle, then the map."""
     from e2ehip.synthetic import make_sequence, tum_intrinsics
     from online_adaption import SLAM
-    H, W, L = 64, 96, 3
+    L = 3
     seq = make_sequence(L, H, W, seed=13, step=0.13, K=tum_intrinsics(H, W), holes=0.1)
     assert float((seq[1] == 0).float().mean()) > 0.05
     sd = depthnet.random_state_dict(0)

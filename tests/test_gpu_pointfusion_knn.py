@@ -326,3 +326,49 @@ def test_resident_map_step_and_index_equal_the_host_visible_forms():
     small.step_resident(c.to(DEV), d.to(DEV), K, _pose().to(DEV))
     with pytest.raises(RuntimeError):
         small.M
+
+
+def test_chamfer_bidirectional_and_colour_loss_values_vs_oracle():
+    """N3 leftovers: ChamferDistance(bidirectional=True) as train_depth.py:690-692 calls it, and
+    knn_points_loss + color_points_loss as gradient_experiments.py:143-150 chains them -- VALUES and gradients against the oracle.
+    The reverse term searches the differentiable cloud, so its gradient is the scatter half of knn_points' backward
+    (e2e_knn1_bwd_ref: fixed-point accumulation, bitwise reproducible)."""
+    from chamferdist import ChamferDistance
+    from loss.losses import color_points_loss, knn_points_loss
+    from oracle import knn as oknn
+    g = torch.Generator().manual_seed(31)
+    src = torch.randn(1, 3000, 3, generator=g) * 0.5
+    tgt = torch.cat([src[:, :2200] + 0.02 * torch.randn(1, 2200, 3, generator=g), torch.randn(1, 300, 3, generator=g)], 1)   # shared neighbours
+    cs, ct = torch.rand(1, 3000, 3, generator=g), torch.rand(1, 2500, 3, generator=g)
+    cd = ChamferDistance()
+    for kw in (dict(bidirectional=True), dict(reverse=True), dict(), dict(bidirectional=True, reduction="sum")):
+        a, b = src.clone().requires_grad_(True), tgt.clone().requires_grad_(True)
+        ref = oknn.chamfer_distance(a, b, **kw)
+        ga, gb = torch.autograd.grad(ref, [a, b], allow_unused=True)
+        x, y = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        outs = []
+        for rep in range(2):
+            val = cd(x, y, **kw)
+            gx, gy = torch.autograd.grad(val, [x, y], allow_unused=True)
+            outs.append((val.detach().clone(), gx, gy))
+        torch.testing.assert_close(outs[0][0].cpu(), ref.detach(), rtol=1e-5, atol=1e-9)
+        for got, want in ((outs[0][1], ga), (outs[0][2], gb)):
+            if want is None:
+                assert got is None or float(got.abs().max()) == 0.0
+            else:
+                torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-7 * float(want.abs().max()) + 1e-12)
+        for p, q in zip(outs[0], outs[1]):                                  # run-to-run: bit for bit (integer accumulation)
+            assert (p is None and q is None) or torch.equal(p, q)
+    # knn_points_loss -> indices -> colour loss (values, indices, gradient wrt the noisy colours)
+    l_ref, i_ref = oknn.knn_points_loss(tgt, src)
+    l_gpu, i_gpu = knn_points_loss(gt_pointcloud=tgt.to(DEV), noisy_pointcloud=src.to(DEV))
+    assert torch.equal(i_gpu.cpu(), i_ref)
+    torch.testing.assert_close(l_gpu.cpu(), l_ref, rtol=1e-5, atol=0)
+    c = cs.clone().requires_grad_(True)
+    c_ref = oknn.color_points_loss(ct, c, i_ref)
+    cg = cs.to(DEV).requires_grad_(True)
+    c_gpu = color_points_loss(ct.to(DEV), cg, i_gpu)
+    torch.testing.assert_close(c_gpu.detach().cpu(), c_ref.detach(), rtol=1e-6, atol=0)
+    torch.testing.assert_close(torch.autograd.grad(c_gpu, cg)[0].cpu(), torch.autograd.grad(c_ref, c)[0], rtol=1e-6, atol=1e-12)
+    with pytest.raises(ValueError):
+        color_points_loss(ct.to(DEV)[..., :2], cg, i_gpu)

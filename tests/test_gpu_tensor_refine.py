@@ -137,6 +137,60 @@ def test_fused_adam_state_round_trip_and_load_optimizer(tmp_path):
     assert ob.steps_done() == 4 and ob.param_groups[0]["lr"] == 3e-3
 
 
+def test_fused_adam_loads_a_partial_torch_adam_state():
+    """a file written by the reference's torch.optim.Adam holds state only for the parameters that had received gradients.
+    Round 3 laid the flat bucket out over exactly those and then never updated any other parameter.  Now the bucket is decided by the
+    gradients / prebuild() as always and the file is applied to it: same gradient pattern -> the next step equals torch's; a trained
+    parameter the file does not know, next to others at step 2 -> ValueError (one step counter cannot run it), never a silent skip."""
+    from e2ehip.optim import FusedAdam
+    g = torch.Generator().manual_seed(12)
+    shapes = [(6, 4), (9,), (2, 3, 3, 3), (5,)]
+    init = [torch.randn(*sh, generator=g) for sh in shapes]
+    grads = [[torch.randn(*sh, generator=g) for sh in shapes] for _ in range(3)]
+    with_grad = (0, 2)                                              # parameters 1 and 3 never see a gradient in the saved run
+
+    def cpu_run(nsteps):
+        ps = [torch.nn.Parameter(t.clone()) for t in init]
+        opt = torch.optim.Adam(ps, lr=2e-3)
+        for k in range(nsteps):
+            opt.zero_grad()
+            for i in with_grad:
+                ps[i].grad = grads[k][i].clone()
+            opt.step()
+        return ps, opt
+
+    ps2, o2 = cpu_run(2)
+    sd = o2.state_dict()
+    assert sorted(sd["state"]) == list(with_grad)
+    ps3, _ = cpu_run(3)
+
+    def gpu(params_with_grad):
+        ps = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ps2]
+        opt = FusedAdam(ps, lr=1.0)
+        opt.load_state_dict(sd)
+        assert sorted(opt.state_dict()["state"]) == list(with_grad)          # loaded, not applied yet: round-trips unchanged
+        for i in params_with_grad:
+            ps[i].grad = grads[2][i].to(DEV).clone()
+        return ps, opt
+
+    ps, opt = gpu(with_grad)
+    opt.step()
+    torch.cuda.synchronize()
+    for a, b in zip(ps, ps3):
+        torch.testing.assert_close(a.detach().cpu(), b.detach(), rtol=1e-6, atol=1e-7)
+    assert opt.steps_done() == 3 and sorted(opt.state_dict()["state"]) == list(with_grad)
+    ps, opt = gpu((0, 1, 2))                                        # parameter 1 trains now but the file has no state for it
+    with pytest.raises(ValueError, match="carry no state"):
+        opt.step()
+    # prebuilt but never stepped: no state entries, like torch; several parameter groups: refused, not half-honoured
+    ps = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    opt = FusedAdam(ps, lr=1e-3)
+    opt.prebuild(ps)
+    assert opt.state_dict()["state"] == {}
+    with pytest.raises(NotImplementedError):
+        FusedAdam([{"params": ps[:2]}, {"params": ps[2:], "lr": 1e-4}], lr=1e-3)
+
+
 def test_map_export_roundtrip(tmp_path):
     from utils.export import load_ply, save_ply
     g = torch.Generator().manual_seed(1)
