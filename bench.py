@@ -35,7 +35,8 @@ MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA, dense (= the
 CONV_ENTRY_POINTS = ("e2e_conv2d_fwd", "e2e_conv2d_bwd_data", "e2e_conv2d_bwd_data_acc", "e2e_conv2d_bwd_data_fused", "e2e_conv2d_bwd_weight",
                      "e2e_conv2d_bwd_weight_scaled")
 WARP_ENTRY_POINTS = ("e2e_warp_photo_lossgrad_hostgeo", "e2e_warp_photo_lossgrad", "e2e_warp_photo_lossgrad_chain")
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r03_bench_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r04_bench_pmc_traffic.json")
+WHOLE_PASS = os.path.join(ROOT, "profiles", "r04_bench_seq_fullpass.json")     # `--steps 177 --warmup 6` line of tools/evidence.sh
 NET_SEED = 20241004         # seed of the depth network's random initialisation (there are no pretrained weights on the GPU box)
 
 
@@ -216,7 +217,7 @@ def seq_bench(a, rank, world, dev):
                "last": {"pass": timed[-1][0], "keyframe": timed[-1][1] + 1, "map_points_before": int(timed[-1][2])},
                "keyframes_in_timed_region": len(timed), "of_keyframes_per_pass": len(sched),
                "note": "keyframe k = k-th pair of the schedule (1-based); KNN / association cost grows with the map, so a short timed region "
-                       "that starts at keyframe 3 reads faster than a whole pass (profiles/r03_bench_seq_fullpass.json = --steps 177)"}
+                       "that starts at keyframe 3 reads faster than a whole pass (value_whole_pass: profiles/r04_bench_seq_fullpass.json = --steps 177)"}
     if world > 1:
         tt = torch.tensor([el], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -309,9 +310,11 @@ def seq_bench(a, rank, world, dev):
     sizes, gathered = [map_points], map_points
     if world > 1:
         t1 = time.perf_counter()
-        g = edist.gather_maps(*slam.map.live())
+        g = edist.gather_maps(*slam.map.live(), dst=0)                 # exact sizes, to rank 0 only
         torch.cuda.synchronize(dev)
-        sizes, gathered = [int(c) for c in g[4]], int(g[0].shape[0])
+        sizes, gathered = [int(c) for c in g[4]], int(sum(int(c) for c in g[4]))
+        if rank == 0 and int(g[0].shape[0]) != gathered:
+            raise RuntimeError("map gather: rank 0 received a different number of points than the ranks reported")
         roof["map_gather_ms"] = 1e3 * (time.perf_counter() - t1)
     if rank == 0:
         out = {"metric": "online refinement steps/sec @640x480, seq_len=60", "value": world * K / el, "unit": "steps/s", "n_gpus": world, "steps": K,
@@ -331,6 +334,19 @@ def seq_bench(a, rank, world, dev):
             out["value"] = None
             out["error"] = "replicas diverged: parameter checksums differ between ranks"
         out.update(roof)
+        out["source_stamp"] = source_stamp()
+        # the default timed region (20 steps from keyframe 3, a small map) reads faster than a whole pass of the 60-frame sequence: the
+        # whole-pass figure travels with this line, with the build it was measured on (tools/evidence.sh runs it first)
+        if world == 1 and a.workload == "seq" and os.path.isfile(WHOLE_PASS):
+            try:
+                with open(WHOLE_PASS) as f:
+                    wp = json.loads([l for l in f.read().splitlines() if l.startswith("{")][-1])
+                out["value_whole_pass"] = {"value": wp["value"], "unit": wp["unit"], "steps": wp["steps"], "ms_per_step": wp["ms_per_step"],
+                                           "keyframes_covered": wp["config"].get("keyframes_covered"), "source_stamp": wp.get("source_stamp"),
+                                           "same_build_as_this_line": wp.get("source_stamp") == out["source_stamp"],
+                                           "file": os.path.relpath(WHOLE_PASS, ROOT), "command": "python3 bench.py --gpus 1 --steps 177 --warmup 6 --no-cpu-baseline"}
+            except Exception as e:                      # a malformed record must not cost the bench line
+                out["value_whole_pass"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_seq(H, W, a.tum)
         print(json.dumps(out))

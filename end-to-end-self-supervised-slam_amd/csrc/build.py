@@ -27,7 +27,8 @@ EXACT = {"pointfusion.hip", "knn.hip", "icp.hip"}          # bit-exact against t
 
 
 def flags_for(src):
-    return FLAGS + ["-ffp-contract=off" if src in EXACT else "-ffp-contract=fast"]
+    mode = os.environ.get("E2E_FP_CONTRACT")           # diagnostics: force one mode for the non-exact files (A/B of the parity tests)
+    return FLAGS + ["-ffp-contract=off" if (src in EXACT or mode == "off") else "-ffp-contract=fast"]
 
 
 def sources():

@@ -27,7 +27,7 @@ __device__ __forceinline__ float key2f(unsigned int k) {
 // ---------------------------------------------------------------------------------------------
 #define MED_BINS 2048
 struct MedState {
-    unsigned int prefix, rank, key, index;
+    unsigned int prefix, rank, key, index, count;      // index: smallest element holding the median value; count: how many hold it
 };
 
 // find the bin that holds rank `r` in hist[0..nb) (nb <= 2048): returns the bin, writes the rank inside the bin.
@@ -109,18 +109,20 @@ __global__ __launch_bounds__(DT) void k_median_final(const float* __restrict__ x
     const unsigned int key = st->prefix | b2;
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->key = key; *value_out = key2f(key); }
     for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT)
-        if (f2key(x[i]) == key) atomicMin(&st->index, (unsigned int)i);
+        if (f2key(x[i]) == key) { atomicMin(&st->index, (unsigned int)i); atomicAdd(&st->count, 1u); }
 }
 
 __global__ void k_median_init(unsigned int* hist, MedState* st) {
     for (int i = threadIdx.x; i < 3 * MED_BINS; i += blockDim.x) hist[i] = 0;
-    if (threadIdx.x == 0) { st->prefix = 0; st->rank = 0; st->key = 0; st->index = 0xFFFFFFFFu; }
+    if (threadIdx.x == 0) { st->prefix = 0; st->rank = 0; st->key = 0; st->index = 0xFFFFFFFFu; st->count = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------
 // disp -> depth and the median-scale chain
 //   delta = 1/disp ; rho = m_gt / median(delta) ; depth = rho * delta           (forward, 2 kernels + median)
-//   g_delta = rho*g + [i == k*] * (-(rho/median) * sum(g*delta)) ; g_disp = -delta^2 * g_delta   (backward)
+//   g_delta = rho*g + [delta_i == median] * (-(rho/median) * sum(g*delta)) / #{j: delta_j == median} ; g_disp = -delta^2 * g_delta   (backward)
+//   torch.median(x) without a dim differentiates as evenly_distribute_backward: the gradient of the median VALUE is shared equally by all
+//   elements that hold it (one element unless values tie exactly).  `elems` (n_elems > 0): the caller names the elements instead.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(DT) void k_reciprocal(const float* __restrict__ disp, float* __restrict__ delta, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT) delta[i] = 1.0f / disp[i];
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(DT) void k_dot_partials(const float* __restrict__ a
 __global__ __launch_bounds__(DT) void k_scale_chain_bwd(const float* __restrict__ g, const float* __restrict__ delta,
                                                         const float* __restrict__ m_gt, const float* __restrict__ m_delta,
                                                         const MedState* __restrict__ st, const float* __restrict__ partials,
-                                                        int nparts, float* __restrict__ g_disp, int64_t n) {
+                                                        int nparts, float* __restrict__ g_disp, int64_t n, const int* __restrict__ elems, int n_elems) {
     __shared__ float sS;
     if (threadIdx.x == 0) {                 // every workgroup re-adds the (few hundred) partials in the same order
         double acc = 0.0;
@@ -157,11 +159,13 @@ __global__ __launch_bounds__(DT) void k_scale_chain_bwd(const float* __restrict_
     __syncthreads();
     const float md = m_delta[0], rho = m_gt[0] / md;
     const float corr = -(rho / md) * sS;
-    const unsigned int kstar = st->index;
+    const float share = corr / (float)(n_elems > 0 ? (unsigned int)n_elems : st->count);
     for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT) {
         const float d = delta[i];
         float gd = rho * g[i];
-        if ((unsigned int)i == kstar) gd += corr;
+        if (n_elems > 0) {
+            for (int e = 0; e < n_elems; ++e) if ((int)i == elems[e]) gd += share;
+        } else if (d == md) gd += share;
         g_disp[i] = -(d * d) * gd;
     }
 }
@@ -304,7 +308,6 @@ static inline int sgrid(int64_t n, int cap = 1024) {
 extern "C" {
 
 int64_t e2e_median_workspace_bytes(void) { return (3 * MED_BINS + 8) * 4; }
-int64_t e2e_median_index_offset_bytes(void) { return (3 * MED_BINS + 3) * 4; }     /* MedState::index */
 
 int e2e_median_lower(const float* x, int64_t n, float* value_out, void* workspace, void* stream) {
     E2E_REQUIRE(n > 0 && n < 0xFFFFFFFFll && x && value_out && workspace, E2E_ERR_ARG, "e2e_median_lower: bad argument");
@@ -373,13 +376,19 @@ int e2e_depth_fixed_scale_bwd(const float* g_depth, const float* disp, float sca
 
 int e2e_depth_scale_bwd(const float* g_depth, const float* delta, const float* median_gt, const float* median_delta,
                         float* g_disp, void* workspace, int64_t n, void* stream) {
+    return e2e_depth_scale_bwd_at(g_depth, delta, median_gt, median_delta, nullptr, 0, g_disp, workspace, n, stream);
+}
+
+int e2e_depth_scale_bwd_at(const float* g_depth, const float* delta, const float* median_gt, const float* median_delta, const int* elements,
+                           int n_elements, float* g_disp, void* workspace, int64_t n, void* stream) {
     E2E_REQUIRE(n > 0 && g_depth && delta && median_gt && median_delta && g_disp && workspace, E2E_ERR_ARG, "e2e_depth_scale_bwd: bad argument");
+    E2E_REQUIRE(n_elements >= 0 && n_elements <= 64 && (n_elements == 0 || elements), E2E_ERR_ARG, "e2e_depth_scale_bwd_at: 0..64 named elements");
     hipStream_t st = (hipStream_t)stream;
     const MedState* ms = (const MedState*)((unsigned int*)workspace + 3 * MED_BINS);
     float* parts = (float*)((char*)workspace + e2e_median_workspace_bytes() + 32);
     const int g = sgrid(n, RED_PARTS);
     hipLaunchKernelGGL(k_dot_partials, dim3(g), dim3(DT), 0, st, g_depth, delta, n, parts);
-    hipLaunchKernelGGL(k_scale_chain_bwd, dim3(sgrid(n)), dim3(DT), 0, st, g_depth, delta, median_gt, median_delta, ms, parts, g, g_disp, n);
+    hipLaunchKernelGGL(k_scale_chain_bwd, dim3(sgrid(n)), dim3(DT), 0, st, g_depth, delta, median_gt, median_delta, ms, parts, g, g_disp, n, elements, n_elements);
     E2E_LAUNCH_CHECK("e2e_depth_scale_bwd");
     return E2E_OK;
 }

@@ -72,11 +72,11 @@ SIGNATURES = {
     "e2e_knn1_bwd": [c_fp, c_fp, c_fp, c_fp, c_i64, c_fp, c_fp],
     "e2e_knn1_bwd_ref": [c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_fp, c_fp, c_fp],
     "e2e_median_workspace_bytes": [],
-    "e2e_median_index_offset_bytes": [],
     "e2e_median_lower": [c_fp, c_i64, c_fp, c_fp, c_fp],
     "e2e_depth_scale_workspace_bytes": [],
     "e2e_depth_scale_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp],
     "e2e_depth_scale_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp],
+    "e2e_depth_scale_bwd_at": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_i64, c_fp],
     "e2e_depth_fixed_scale_fwd": [c_fp, c_f32, c_fp, c_fp, c_i64, c_fp],
     "e2e_depth_fixed_scale_bwd": [c_fp, c_fp, c_f32, c_fp, c_i64, c_fp],
     "e2e_reduce_workspace_floats": [],
@@ -138,7 +138,7 @@ SIGNATURES = {
 }
 _RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats": c_i64,
             "e2e_warp_photo_lossgrad_workspace_floats": c_i64, "e2e_pf_workspace_bytes": c_i64,
-            "e2e_knn1_workspace_bytes": c_i64, "e2e_knn1_index_capacity_bytes": c_i64, "e2e_median_workspace_bytes": c_i64, "e2e_median_index_offset_bytes": c_i64,
+            "e2e_knn1_workspace_bytes": c_i64, "e2e_knn1_index_capacity_bytes": c_i64, "e2e_median_workspace_bytes": c_i64,
             "e2e_depth_scale_workspace_bytes": c_i64, "e2e_reduce_workspace_floats": c_i64,
             "e2e_conv2d_wgrad_workspace_floats": c_i64, "e2e_conv2d_wgrad_tuned_workspace_floats": c_i64, "e2e_conv_tuned_workspace_floats": c_i64, "e2e_conv2d_splitk_workspace_floats": c_i64, "e2e_conv2d_bwd_data_workspace_floats": c_i64,
             "e2e_head_workspace_floats": c_i64, "e2e_icp_workspace_bytes": c_i64, "e2e_aux_workspace_floats": c_i64,

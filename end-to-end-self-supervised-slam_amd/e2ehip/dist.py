@@ -127,19 +127,63 @@ def common_rounds(n_local, device):
     return int(t.item())
 
 
-def gather_maps(points, normals, colors, ccounts):
-    """Variable-length all-gather of the per-rank maps -> concatenated (points, normals, colors, ccounts, counts)."""
+def _broadcast(t, src):
+    if t.is_cuda and _host_staged():
+        h = t.cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+
+
+def gather_maps(points, normals, colors, ccounts, dst=None):
+    """End of a run: the per-rank maps (variable length) -> (points, normals, colors, ccounts, counts), rank after rank.
+    dst=None: every rank receives the whole gathered map; dst=r: only rank r does (the others get None for the four arrays and the
+    per-rank counts).  Exact sizes: after ONE small all-gather of the counts the receiver allocates sum(counts) rows per array and every
+    rank's rows travel straight into their slice -- one broadcast (dst=None) or one send / receive (dst=r) per array and rank, no
+    padding, no staging copy.  (Round 3 padded every rank's map to the largest one and materialised world x largest x 40 B on every
+    rank, plus a packed copy and a concatenation: 8 x 470 MB x 3 for a full pass on 8 ranks, to report a size.)"""
+    arrays = (points, normals, colors, ccounts)
     if world() == 1:
         return points, normals, colors, ccounts, torch.tensor([points.shape[0]])
-    dev = points.device
+    dev, w, me = points.device, world(), dist.get_rank()
     n = torch.tensor([points.shape[0]], device=dev, dtype=torch.int64)
-    counts = [torch.zeros_like(n) for _ in range(world())]
+    counts = [torch.zeros_like(n) for _ in range(w)]
     _all_gather(counts, n)
-    counts = torch.cat(counts)
-    cap = int(counts.max())
-    packed = torch.zeros(cap, 10, device=dev, dtype=torch.float32)          # 40 B per point
-    packed[: points.shape[0]] = torch.cat([points, normals, colors, ccounts.reshape(-1, 1)], 1)
-    parts = [torch.empty_like(packed) for _ in range(world())]
-    _all_gather(parts, packed)
-    full = torch.cat([p[: int(c)] for p, c in zip(parts, counts)], 0)
-    return full[:, 0:3], full[:, 3:6], full[:, 6:9], full[:, 9], counts.cpu()
+    counts = torch.cat(counts).cpu()
+    offs = [0]
+    for c in counts.tolist():
+        offs.append(offs[-1] + int(c))
+    receive = dst is None or me == dst
+    outs = [torch.empty((offs[-1],) + tuple(a.shape[1:]), device=dev, dtype=a.dtype) for a in arrays] if receive else [None] * 4
+    for r in range(w):
+        lo, hi = offs[r], offs[r + 1]
+        if hi == lo:
+            continue
+        for k, a in enumerate(arrays):
+            if dst is None:
+                buf = outs[k][lo:hi]                                # a contiguous slice of the result: received in place
+                if r == me:
+                    buf.copy_(a)
+                _broadcast(buf, r)
+            elif me == dst:
+                if r == me:
+                    outs[k][lo:hi].copy_(a)
+                else:
+                    _recv(outs[k][lo:hi], r)
+            elif r == me:
+                _send(a.contiguous(), dst)
+    return outs[0], outs[1], outs[2], outs[3], counts
+
+
+def _send(t, dst):
+    dist.send(t.cpu() if (t.is_cuda and _host_staged()) else t, dst=dst)
+
+
+def _recv(t, src):
+    if t.is_cuda and _host_staged():
+        h = torch.empty(t.shape, dtype=t.dtype)
+        dist.recv(h, src=src)
+        t.copy_(h)
+    else:
+        dist.recv(t, src=src)

@@ -65,11 +65,9 @@ class RefineStepPlan:
         self.g3 = torch.zeros(1, 1, H, W, **f)
         self.ws_aux = torch.empty(lib.e2e_aux_workspace_floats(), **f)
         self._graphs, self._gstream = {}, None
-        # the uint32 inside ws_scale that names the median ELEMENT of the predictions -- where the ratio's gradient lands
-        # (online_adaption.py:295-298; torch.median's `indices`).  median_index_override (a device int32[1], tests): written there between
-        # the forward and the backward of a step, to make the choice among near-tied elements the oracle's instead of this kernel's
-        self._median_slot = self.ws_scale.view(torch.int32)[lib.e2e_median_index_offset_bytes() // 4: lib.e2e_median_index_offset_bytes() // 4 + 1]
-        self.median_index_override = None
+        # tests: device int32 indices (into the stacked (2,1,H,W) predictions) of the elements the CPU evaluation's torch.median holds
+        # as the median -- the ratio's gradient then lands on exactly those (e2e_depth_scale_bwd_at) instead of on this evaluation's own
+        self.median_elements_override = None
         self.net.refresh_layouts()
 
     # ---- per keyframe -----------------------------------------------------------------------------------------------------
@@ -141,8 +139,9 @@ class RefineStepPlan:
         self.loss.step()                                            # losses -> self.loss.loss[0..1]; d/d depth -> self.g_depth
         if use_3d:                                                  # g_depth_tgt += d(w_3d * l3)/d depth_tgt
             L.call("e2e_conv2d_act_bwd_acc", L.ptr(self.g3), L.ptr(self.g3), None, L.ptr(self.g_depth[1:2]), self.N, 1, 0, 1, st)
-        L.call("e2e_depth_scale_bwd", L.ptr(self.g_depth), L.ptr(self.delta), L.ptr(self.median_gt), L.ptr(self.md), L.ptr(self.net.disp.g),
-               L.ptr(self.ws_scale), self.g_depth.numel(), st)
+        ov = self.median_elements_override
+        L.call("e2e_depth_scale_bwd_at", L.ptr(self.g_depth), L.ptr(self.delta), L.ptr(self.median_gt), L.ptr(self.md), L.ptr(ov),
+               0 if ov is None else int(ov.numel()), L.ptr(self.net.disp.g), L.ptr(self.ws_scale), self.g_depth.numel(), st)
         if late_only:                                               # data-parallel runs: head, decoder, layer4 -- the bucket's tail
             self.net.backward_late_layers()
             return
@@ -162,8 +161,6 @@ class RefineStepPlan:
         self._run("fwd", self._forward)
         if first_step and self.reg:
             self.init.copy_(self.delta)
-        if self.median_index_override is not None:
-            self._median_slot.copy_(self.median_index_override)
         # the 3-D loss against a RESIDENT index (e2ehip.fusionmap: one buffer per run, map size on the device) has constant launch
         # arguments and rides in the backward graph; any other index object is queried eagerly here
         cap_idx, ikey = None, None
@@ -173,7 +170,8 @@ class RefineStepPlan:
         elif use_3d:
             self._loss3d(knn_index)
         if not edist.data_parallel():
-            self._run(("bwd", use_3d, True, ikey), lambda: self._backward(use_3d, True, index=cap_idx, warm=warm))
+            okey = None if self.median_elements_override is None else (self.median_elements_override.data_ptr(), self.median_elements_override.numel())
+            self._run(("bwd", use_3d, True, ikey, okey), lambda: self._backward(use_3d, True, index=cap_idx, warm=warm))
         else:
             # data-parallel: the exchange of the bucket's tail (head, decoder, layer4: 80 % of the bytes, complete after the first
             # part of the backward pass) travels while the early layers' backward computes; then the remaining 20 %, then Adam
@@ -231,10 +229,6 @@ class RefineStepPlan:
         self._graphs.clear()
         self.net.close()
         self._closed = True
-
-    def median_index(self):
-        """Flat index (into the stacked (2,1,H,W) predictions) of the element the last forward chose as the median (device int32[1])."""
-        return self._median_slot
 
     def losses(self):
         """(photometric mean, regulariser sum of means, 3-D loss mean) of the last step as device tensors (no sync)."""

@@ -178,7 +178,7 @@ class SLAM:
             print(torch.tensor(self.mean_abs).mean().item())
         self.map.check_capacity()               # the one host read of the map size (and of its overflow flag) of the whole run
         if edist.world() > 1:                   # end of run: variable-length gather of the per-rank maps
-            self.gathered_map = edist.gather_maps(*self.map.live())
+            self.gathered_map = edist.gather_maps(*self.map.live(), dst=0)     # rank 0 receives the maps, every rank their sizes
         return self.map
 
     def close(self):

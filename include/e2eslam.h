@@ -313,20 +313,18 @@ int e2e_knn1_index_query_dev_image_warm(const float* p1, int64_t n1, int row_len
 
 /* torch.median over all elements (online_adaption.py:295,343): the LOWER median (rank (n-1)/2) by
  * radix select; *value_out (device).  workspace: e2e_median_workspace_bytes() bytes; afterwards it
- * also holds the smallest index whose value equals the median (used by the scale chain's autograd). */
+ * also holds the smallest index whose value equals the median and the number of elements that hold it (used by
+ * the scale chain's autograd). */
 int64_t e2e_median_workspace_bytes(void);
-/* Byte offset, inside the workspace, of the uint32 that names that element: the second result of torch.median(x, 0)
- * (`indices`), i.e. the element autograd routes the ratio's gradient to (online_adaption.py:295-298).  A caller may read
- * it after e2e_median_lower / e2e_depth_scale_fwd, and may overwrite it before e2e_depth_scale_bwd to name another
- * element of equal value (torch returns "one index" among ties; this library the smallest). */
-int64_t e2e_median_index_offset_bytes(void);
 int e2e_median_lower(const float* x, int64_t n, float* value_out, void* workspace, void* stream);
 
 /* online_adaption.py:282,292-298 for the n = F*H*W elements of the stacked disparities:
  *   delta = 1/disp ; ratio = median_gt / median(delta) ; depth = ratio * delta.
  * median_gt, median_delta, ratio_out are device scalars.  The backward is the exact autograd chain,
  * including the term torch routes to the element that IS the median:
- *   g_delta = ratio*g + [i==k*] * (-(ratio/median_delta) * sum(g*delta)) ; g_disp = -delta^2 g_delta.
+ *   g_delta = ratio*g + [delta_i == median] * (-(ratio/median_delta) * sum(g*delta)) / #{delta_j == median} ;
+ *   g_disp = -delta^2 g_delta      (torch.median(x) differentiates as evenly_distribute_backward: the elements that HOLD
+ *   the median value share its gradient equally -- one element unless values tie exactly).
  * workspace (shared by fwd and bwd of one step): e2e_depth_scale_workspace_bytes() bytes. */
 int64_t e2e_depth_scale_workspace_bytes(void);
 int e2e_depth_scale_fwd(const float* disp, const float* median_gt, float* delta, float* depth,
@@ -335,6 +333,14 @@ int e2e_depth_scale_fwd(const float* disp, const float* median_gt, float* delta,
 int e2e_depth_scale_bwd(const float* g_depth, const float* delta, const float* median_gt,
                         const float* median_delta, float* g_disp, void* workspace, int64_t n,
                         void* stream);
+/* The same chain with the elements that receive the median's gradient NAMED by the caller (device int32 indices into the
+ * n stacked predictions, 1..64 of them, sharing the gradient equally; n_elements == 0: e2e_depth_scale_bwd).  For callers
+ * that hold torch.median's own choice: among 614 400 fp32 depths the neighbours of the median lie ~1e-6 apart, closer than two
+ * correct evaluations of the network agree, so WHICH element it is belongs to the evaluation, not to the algorithm --
+ * the parity tests name the CPU evaluation's elements here and compare everything else (online_adaption.py:295-298). */
+int e2e_depth_scale_bwd_at(const float* g_depth, const float* delta, const float* median_gt,
+                           const float* median_delta, const int* elements, int n_elements,
+                           float* g_disp, void* workspace, int64_t n, void* stream);
 
 /* The fixed-scale form of train_depth.py:331-345 (`depth = 1 / disp` then `depth *= ABLATION.scaling_depth`): delta = 1 / disp
  * (may be NULL), depth = delta * scale; backward g_disp = -(g_depth * scale) / disp^2. */

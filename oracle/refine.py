@@ -78,7 +78,11 @@ class Refiner:
             # (test diagnostics) which element IS the lower median of the stacked predictions: the ratio's backward puts a sum over all
             # pixels on that one element, so two evaluations that pick different (near-tied) elements have different -- equally valid --
             # parameter gradients; tests compare those only when the element agrees
-            median_index = int(torch.cat([d.detach().reshape(-1) for d in depths]).median(0).indices)
+            stacked = torch.cat([d.detach().reshape(-1) for d in depths])
+            median_index = int(stacked.median(0).indices)
+            # torch.median(x) (no dim, as online_adaption.py:295 calls it) differentiates as evenly_distribute_backward: ALL elements equal
+            # to the median value share its gradient
+            median_indices = (stacked == stacked.median()).nonzero().reshape(-1).tolist()
             depths, ratio = warp_loss.median_scale(depths, gt_depths)  # (:292-298)
             for d in depths:
                 d.retain_grad()                                        # (test diagnostics) d loss / d scaled depth, rec["g_depth"]
@@ -106,6 +110,7 @@ class Refiner:
             self.opt.step()
             rec["loss"] = loss.item()
             rec["median_index"] = median_index
+            rec["median_indices"] = median_indices
             rec["g_depth"] = [d.grad.detach().clone() for d in depths]
             rec["depth1"] = depths[1].detach()
             rec["metrics"] = [m.item() for m in warp_loss.depth_metrics(cfg.dataset, gt_depths[0][1], depths[1][0])]

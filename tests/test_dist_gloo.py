@@ -61,6 +61,10 @@ def _worker(rank, world, port, q):
     gp, gn, gc, gcc, counts = edist.gather_maps(P, Nn, C, cc)
     ok5 = gp.shape[0] == sum(r + 2 for r in range(world)) and counts.tolist() == [r + 2 for r in range(world)] and \
         torch.equal(gp[:2], torch.zeros(2, 3)) and torch.equal(gp[2:], torch.ones(3, 3)) and torch.equal(gcc, torch.tensor([0., 1, 0, 1, 2]))
+    # ... to one rank only (exact sizes, point-to-point): the others receive nothing but the counts
+    gp1, _, _, gcc1, counts1 = edist.gather_maps(P, Nn, C, cc, dst=1)
+    ok5 = ok5 and counts1.tolist() == counts.tolist() and ((gp1 is None and gcc1 is None) if rank != 1 else
+                                                          (torch.equal(gp1, gp) and torch.equal(gcc1, gcc)))
     # (6) the launch plan's two-segment form: tail [split, end) + participant count asynchronously, then the head [0, split);
     #     rank 1 idles (zero bucket) -- and the parameter broadcast that makes the replicas start identical
     flat.zero_grad()
@@ -161,3 +165,90 @@ def test_forced_exchange_on_one_rank_is_the_identity():
     res = q.get(timeout=120)
     p.join(60)
     assert res == (False, False, True, True, False)
+
+
+def _ordering_worker(rank, world, port, q):
+    """The two-segment exchange as RefineStepPlan.step issues it (late backward -> asynchronous all-reduce of the bucket's tail -> early
+    backward -> all-reduce of the head -> wait -> Adam), with the asynchronous collective made as late as the protocol allows: the
+    handle performs the tail's all-reduce only inside wait().  Whatever touches the tail between the issue and the wait, and whoever reads
+    it before the wait, then changes the outcome deterministically."""
+    sys.path[:0] = [ROOT, PKG]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from e2ehip import dist as edist
+    from e2ehip.optim import FlatParams
+    torch.manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(6, 4)), torch.nn.Parameter(torch.randn(8)), torch.nn.Parameter(torch.randn(3, 2, 3, 3)), torch.nn.Parameter(torch.randn(12))]
+    flat = FlatParams(ps)
+    split = flat.offsets[2]                              # "late layers" = the last two parameters = the bucket's tail
+    g = torch.Generator().manual_seed(10 + rank)
+    grad = torch.randn(flat.numel, generator=g)
+    want = grad.clone()
+    dist.all_reduce(want)                                # the one-shot reference: sum over the ranks
+    real, events = dist.all_reduce, []
+
+    class Lazy:
+        def __init__(self, t, op):
+            self.t, self.op = t, op
+
+        def wait(self):
+            events.append("wait tail")
+            real(self.t, op=self.op)
+
+    def patched(t, op=dist.ReduceOp.SUM, async_op=False):
+        if async_op:
+            events.append("issue tail")
+            return Lazy(t, op)
+        events.append("reduce head")
+        return real(t, op=op)
+
+    def step(early_work):
+        flat.grad_ext.zero_()
+        flat.grad[split:] = grad[split:]                 # late backward: head / decoder / layer4 gradients -- the tail
+        h = edist.exchange_gradients_late_(flat, split, True)
+        early_work()                                     # early backward: layer3 ... stem, while the tail travels
+        cnt = edist.exchange_gradients_early_(flat, split, h, True)
+        return flat.grad.clone(), float(cnt)             # what Adam reads
+
+    edist.dist.all_reduce = patched
+    try:
+        def correct():
+            flat.grad[:split] = grad[:split]             # the early layers' parameters are the bucket's head (NetPlan.split_offset checks it)
+        got, cnt = step(correct)
+        ok_result = torch.equal(got, want) and cnt == float(world)
+        ok_order = events == ["issue tail", "reduce head", "wait tail"]       # the wait sits behind the head's reduction, before the return
+        # negative controls: the test bites.  (a) early work that strays into the tail; (b) a consumer that does not wait
+        def strays():
+            correct()
+            flat.grad[split + 1] += 1.0
+        bad, _ = step(strays)
+        bites_a = not torch.equal(bad, want)
+        flat.grad_ext.zero_()
+        flat.grad[split:] = grad[split:]
+        h = edist.exchange_gradients_late_(flat, split, True)
+        correct()
+        unwaited = flat.grad.clone()                      # read before exchange_gradients_early_ / wait
+        edist.exchange_gradients_early_(flat, split, h, True)
+        bites_b = not torch.equal(unwaited[split:], want[split:])
+    finally:
+        edist.dist.all_reduce = real
+    q.put((rank, ok_result, ok_order, bites_a, bites_b))
+    dist.destroy_process_group()
+
+
+def test_two_segment_exchange_ordering():
+    """the late segment's asynchronous all-reduce is issued between two graph replays; nothing tested that the bucket's
+    tail is left alone until handle.wait() and that wait() precedes the optimiser.  world_size 2, gloo, the asynchronous handle deferred to its
+    wait(): the exchanged bucket equals the one-shot all-reduce bit for bit, the call order is issue-tail / reduce-head / wait-tail, and
+    both ordering mistakes (early work writing into the tail; reading before the wait) change the result."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ordering_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=90) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True, True, True, True), (1, True, True, True, True)], res

@@ -14,13 +14,15 @@ export TMPDIR=/tmp
 TAG=$1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/evidence_$TAG; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-# PMC traffic FIRST: bench.py reports roofline.traffic from profiles/r03_bench_pmc_traffic.json only if that record carries the stamp of the build it runs
+# PMC traffic FIRST: bench.py reports roofline.traffic from profiles/r04_bench_pmc_traffic.json only if that record carries the stamp of the build it runs
 bash tools/bench_pmc.sh $TAG > $OUT/pmc.log 2>&1
 cp gpurun_out/benchpmc_$TAG/traffic.txt $OUT/pmc_traffic.txt; cp gpurun_out/benchpmc_$TAG/traffic.json $OUT/pmc_traffic.json
-cp gpurun_out/benchpmc_$TAG/traffic.json profiles/r03_bench_pmc_traffic.json
+cp gpurun_out/benchpmc_$TAG/traffic.json profiles/r04_bench_pmc_traffic.json
 echo "pmc done" > $OUT/progress.txt
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default $?" >> $OUT/progress.txt
+# whole pass BEFORE the default line: the default line embeds it (value_whole_pass) with the stamp of the build it was measured on
 python3 bench.py --gpus 1 --steps 177 --warmup 6 --no-cpu-baseline > $OUT/bench_fullpass.json 2> $OUT/bench_fullpass.err; echo "fullpass $?" >> $OUT/progress.txt
+cp $OUT/bench_fullpass.json profiles/r04_bench_seq_fullpass.json
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default $?" >> $OUT/progress.txt
 E2E_WGRAD_OVERLAP=1 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/bench_overlap.json 2> $OUT/bench_overlap.err; echo "overlap $?" >> $OUT/progress.txt
 timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --odom gradicp > $OUT/bench_gradicp.json 2> $OUT/bench_gradicp.err; echo "gradicp $?" >> $OUT/progress.txt
 rocprofv3 --kernel-trace --stats -d /tmp/ev_$TAG -o full --output-format csv -- python3 bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
