@@ -53,7 +53,177 @@ __global__ void k_icp_final(const double* __restrict__ partials, int nparts, dou
     out[k] = s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The Gauss-Newton / Levenberg-Marquardt update ON THE DEVICE (round 4): the 6x6 solve, the se(3) exponential, GradICP's smooth
+// damping update and the pose composition in float64 by one thread, so that the numiters iterations of a keyframe's odometry are a
+// fixed launch sequence with no host round trip (round 3: one 232-byte read-back + np.linalg.solve + upload per reduction, 40 per
+// keyframe, 9.4 ms per refinement step).  Same arithmetic as oracle/icp.py: LU with partial pivoting (what numpy's solve calls),
+// Rodrigues + the V matrix with the small-angle branch below 1e-8.
+// state (float64): [0..15] T (row-major), [16..21] xi, [22] lambda, [23] err/cnt of the first reduction, [24] stopped, [25] iterations
+// done, [26] damp, [32 + 2k], [33 + 2k]: (inlier count, sum r^2) of iteration k (trace, up to ICP_TRACE iterations)
+// ---------------------------------------------------------------------------------------------
+#define ICP_TRACE 64
+#define ICP_STATE (32 + 2 * ICP_TRACE)
+
+__device__ void icp_se3_exp(const double* xi, double* T) {
+    const double v[3] = {xi[0], xi[1], xi[2]}, w[3] = {xi[3], xi[4], xi[5]};
+    const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double W2[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) W2[r * 3 + c] = W[r * 3] * W[c] + W[r * 3 + 1] * W[3 + c] + W[r * 3 + 2] * W[6 + c];
+    double a, b, c2;       // R = I + a W + b W^2 ; V = I + b W + c2 W^2
+    if (th < 1e-8) { a = 1.0; b = 0.5; c2 = 1.0 / 6.0; }
+    else { a = sin(th) / th; b = (1.0 - cos(th)) / (th * th); c2 = (th - sin(th)) / (th * th * th); }
+    double V[9];
+    for (int i = 0; i < 9; ++i) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        T[(i / 3) * 4 + (i % 3)] = I + a * W[i] + b * W2[i];
+        V[i] = I + b * W[i] + c2 * W2[i];
+    }
+    for (int r = 0; r < 3; ++r) T[r * 4 + 3] = V[r * 3] * v[0] + V[r * 3 + 1] * v[1] + V[r * 3 + 2] * v[2];
+    T[12] = T[13] = T[14] = 0.0;
+    T[15] = 1.0;
+}
+
+// x = A^-1 b for a 6x6 system, LU with partial pivoting (row swaps on the largest |pivot| of the column)
+__device__ void icp_solve6(double* A, double* b, double* x) {
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        double big = fabs(A[k * 6 + k]);
+        for (int r = k + 1; r < 6; ++r)
+            if (fabs(A[r * 6 + k]) > big) { big = fabs(A[r * 6 + k]); p = r; }
+        if (p != k) {
+            for (int c = 0; c < 6; ++c) { const double t = A[k * 6 + c]; A[k * 6 + c] = A[p * 6 + c]; A[p * 6 + c] = t; }
+            const double t = b[k]; b[k] = b[p]; b[p] = t;
+        }
+        for (int r = k + 1; r < 6; ++r) {
+            const double f = A[r * 6 + k] / A[k * 6 + k];
+            for (int c = k; c < 6; ++c) A[r * 6 + c] -= f * A[k * 6 + c];
+            b[r] -= f * b[k];
+        }
+    }
+    for (int r = 5; r >= 0; --r) {
+        double s = b[r];
+        for (int c = r + 1; c < 6; ++c) s -= A[r * 6 + c] * x[c];
+        x[r] = s / A[r * 6 + r];
+    }
+}
+
+__device__ void icp_compose(const double* step, double* state, float* T32, const float* prev_pose, float* pose_out) {
+    double Tn[16];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += step[r * 4 + k] * state[k * 4 + c];
+            Tn[r * 4 + c] = s;
+        }
+    for (int i = 0; i < 16; ++i) { state[i] = Tn[i]; T32[i] = (float)Tn[i]; }
+    if (pose_out)
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) {
+                double s = 0.0;
+                for (int k = 0; k < 4; ++k) s += Tn[r * 4 + k] * (double)prev_pose[k * 4 + c];
+                pose_out[r * 4 + c] = (float)s;
+            }
+}
+
+__global__ void k_icp_init(double* state, float* T32, float* step32, const float* prev_pose, float* pose_out, double damp) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < ICP_STATE; ++i) state[i] = 0.0;
+    for (int i = 0; i < 16; ++i) { const double v = (i % 5 == 0) ? 1.0 : 0.0; state[i] = v; T32[i] = (float)v; step32[i] = (float)v; }
+    state[22] = damp;
+    state[26] = damp;
+    if (pose_out) for (int i = 0; i < 16; ++i) pose_out[i] = prev_pose[i];
+}
+
+// mode 0 = icp (phase 0 only), 1 = gradicp (phase 0: solve + trial step; phase 1: damping update from the trial step's error, gated step)
+__global__ void k_icp_update(const double* __restrict__ out29, double* __restrict__ state, float* __restrict__ T32, float* __restrict__ step32,
+                             const float* __restrict__ prev_pose, float* __restrict__ pose_out, int mode, int phase, double lambda_max,
+                             double B, double B2, double nu) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (state[24] != 0.0) return;                          // stopped (fewer than 6 inliers at some iteration): the pose stays
+    const double cnt = out29[27], err = out29[28];
+    double step[16];
+    if (phase == 0) {
+        if (cnt < 6.0) {
+            state[24] = 1.0;
+            for (int i = 0; i < 16; ++i) step32[i] = (i % 5 == 0) ? 1.f : 0.f;
+            return;
+        }
+        double A[36], b[6], xi[6];
+        int k = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) { A[r * 6 + c] = A[c * 6 + r] = out29[k]; ++k; }
+        for (int r = 0; r < 6; ++r) { A[r * 6 + r] += state[22]; b[r] = out29[21 + r]; }
+        icp_solve6(A, b, xi);
+        for (int r = 0; r < 6; ++r) state[16 + r] = xi[r];
+        const int it = (int)state[25];
+        if (it < ICP_TRACE) { state[32 + 2 * it] = cnt; state[33 + 2 * it] = err; }
+        icp_se3_exp(xi, step);
+        if (mode == 0) {
+            icp_compose(step, state, T32, prev_pose, pose_out);
+            state[25] += 1.0;
+        } else {
+            state[23] = err / (cnt > 1.0 ? cnt : 1.0);
+            for (int i = 0; i < 16; ++i) step32[i] = (float)step[i];
+        }
+    } else {
+        const double delta = err / (cnt > 1.0 ? cnt : 1.0) - state[23];
+        state[22] *= 1.0 / lambda_max + (lambda_max - 1.0 / lambda_max) / (1.0 + B * exp(-B2 * nu * delta));
+        double z = nu * delta;
+        z = z < -60.0 ? -60.0 : (z > 60.0 ? 60.0 : z);
+        const double gate = 1.0 / (1.0 + exp(z));
+        double xi[6];
+        for (int r = 0; r < 6; ++r) xi[r] = gate * state[16 + r];
+        icp_se3_exp(xi, step);
+        icp_compose(step, state, T32, prev_pose, pose_out);
+        state[25] += 1.0;
+    }
+}
+
+// source cloud of the odometry: every dsratio-th pixel (both directions) of the live frame's world vertex map, row-major.
+// gradslam drops pixels without depth; a resident launch sequence has a fixed number of queries, so a pixel without depth raises
+// *status instead (network-predicted depths 1 / disp are positive everywhere: it never fires on the path this serves).
+__global__ __launch_bounds__(256) void k_icp_source(const float* __restrict__ Vg, const float* __restrict__ depth, int H, int W, int ds,
+                                                    float* __restrict__ src, int* __restrict__ status) {
+    const int hs = (H + ds - 1) / ds, wsub = (W + ds - 1) / ds;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hs * wsub; i += gridDim.x * 256) {
+        const int64_t q = (int64_t)(i / wsub) * ds * W + (int64_t)(i % wsub) * ds;
+        if (depth[q] == 0.f) atomicOr(status, 1);
+        src[i * 3 + 0] = Vg[q * 3 + 0];
+        src[i * 3 + 1] = Vg[q * 3 + 1];
+        src[i * 3 + 2] = Vg[q * 3 + 2];
+    }
+}
+
 extern "C" {
+
+int64_t e2e_icp_state_doubles(void) { return ICP_STATE; }
+
+int e2e_icp_state_init(double* state, float* T32, float* step32, const float* prev_pose, float* pose_out, double damp, void* stream) {
+    E2E_REQUIRE(state && T32 && step32 && (!pose_out || prev_pose), E2E_ERR_ARG, "e2e_icp_state_init: bad argument");
+    hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, (hipStream_t)stream, state, T32, step32, prev_pose, pose_out, damp);
+    E2E_LAUNCH_CHECK("e2e_icp_state_init");
+    return E2E_OK;
+}
+
+int e2e_icp_update(const double* out29, double* state, float* T32, float* step32, const float* prev_pose, float* pose_out, int mode, int phase,
+                   double lambda_max, double B, double B2, double nu, void* stream) {
+    E2E_REQUIRE(out29 && state && T32 && step32 && (!pose_out || prev_pose), E2E_ERR_ARG, "e2e_icp_update: null pointer");
+    E2E_REQUIRE((mode == 0 && phase == 0) || (mode == 1 && (phase == 0 || phase == 1)), E2E_ERR_ARG, "e2e_icp_update: mode 0 (icp, phase 0) or 1 (gradicp, phase 0 / 1)");
+    hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, (hipStream_t)stream, out29, state, T32, step32, prev_pose, pose_out, mode, phase, lambda_max, B, B2, nu);
+    E2E_LAUNCH_CHECK("e2e_icp_update");
+    return E2E_OK;
+}
+
+int e2e_icp_source_subsample(const float* Vg, const float* depth, int H, int W, int dsratio, float* src, int* status, void* stream) {
+    E2E_REQUIRE(Vg && depth && src && status && H > 0 && W > 0 && dsratio > 0, E2E_ERR_ARG, "e2e_icp_source_subsample: bad argument");
+    const int n = ((H + dsratio - 1) / dsratio) * ((W + dsratio - 1) / dsratio);
+    hipLaunchKernelGGL(k_icp_source, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, Vg, depth, H, W, dsratio, src, status);
+    E2E_LAUNCH_CHECK("e2e_icp_source_subsample");
+    return E2E_OK;
+}
 
 #define ICP_MAX_PARTS 256
 int64_t e2e_icp_workspace_bytes(void) { return (int64_t)ICP_MAX_PARTS * ICP_NACC * 8; }

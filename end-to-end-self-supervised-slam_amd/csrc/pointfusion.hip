@@ -587,6 +587,80 @@ int e2e_pf_associate_dev(const float* map_points, const float* map_normals, cons
     return E2E_OK;
 }
 
+// ---- frame-to-model odometry: the ACTIVE map points (find_active_map_points) of the last association, every dsratio-th of them in
+// ascending map order (gradslam: downsample_pointclouds(pc, pc2im_bnhw, dsratio) = pc2im_bnhw[::dsratio]), gathered with their normals
+// into a dense target cloud.  The live map size and the number of targets are DEVICE data. ----
+__global__ __launch_bounds__(PF_T) void k_cp_count_active_dev(int64_t cap, const long long* __restrict__ count_dev, const unsigned char* __restrict__ flags,
+                                                              unsigned int* __restrict__ counts) {
+    __shared__ unsigned int sh[PF_T / 64];
+    const int64_t M = *count_dev < cap ? *count_dev : cap;
+    const int64_t base = (int64_t)blockIdx.x * CP_BLOCK + (int64_t)threadIdx.x * CP_ITEMS;
+    unsigned int c = 0;
+#pragma unroll
+    for (int j = 0; j < CP_ITEMS; ++j)
+        if (base + j < M && flags[base + j] != 0) ++c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(PF_T) void k_gather_active_sub(int64_t cap, const long long* __restrict__ count_dev, const unsigned char* __restrict__ flags,
+                                                            const unsigned int* __restrict__ offsets, int ds, const float* __restrict__ points,
+                                                            const float* __restrict__ normals, float* __restrict__ tgt, float* __restrict__ tgt_n,
+                                                            int64_t tgt_capacity, long long* __restrict__ tgt_count /* {targets, active points, overflow} */) {
+    __shared__ unsigned int sh[PF_T / 64];
+    const int64_t M = *count_dev < cap ? *count_dev : cap;
+    const int64_t base = (int64_t)blockIdx.x * CP_BLOCK + (int64_t)threadIdx.x * CP_ITEMS;
+    bool pr[CP_ITEMS];
+    unsigned int c = 0;
+#pragma unroll
+    for (int j = 0; j < CP_ITEMS; ++j) {
+        pr[j] = base + j < M && flags[base + j] != 0;
+        c += pr[j];
+    }
+    unsigned int o = offsets[blockIdx.x] + cp_block_offset(c, sh);
+#pragma unroll
+    for (int j = 0; j < CP_ITEMS; ++j)
+        if (pr[j]) {
+            if (o % (unsigned int)ds == 0) {
+                const int64_t r = o / (unsigned int)ds, n = base + j;
+                if (r < tgt_capacity) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { tgt[r * 3 + k] = points[n * 3 + k]; tgt_n[r * 3 + k] = normals[n * 3 + k]; }
+                } else {
+                    tgt_count[2] = 1;
+                }
+            }
+            ++o;
+        }
+}
+
+__global__ void k_active_sub_count(long long* __restrict__ tgt_count, int ds, long long tgt_capacity) {
+    const long long P = tgt_count[1];
+    long long t = (P + ds - 1) / ds;
+    tgt_count[0] = t > tgt_capacity ? tgt_capacity : t;
+}
+
+int e2e_pf_active_subsample_dev(const float* map_points, const float* map_normals, const long long* map_count_dev, int64_t map_capacity,
+                                void* workspace, int H, int W, int dsratio, float* tgt, float* tgt_normals, long long* tgt_count_dev,
+                                int64_t tgt_capacity, void* stream) {
+    E2E_REQUIRE(map_points && map_normals && map_count_dev && workspace && tgt && tgt_normals && tgt_count_dev, E2E_ERR_ARG,
+                "e2e_pf_active_subsample_dev: null pointer");
+    E2E_REQUIRE(map_capacity > 0 && dsratio > 0 && tgt_capacity > 0 && H > 0 && W > 0, E2E_ERR_ARG, "e2e_pf_active_subsample_dev: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const PfWs w = pf_ws(workspace, map_capacity, H, W);
+    const int nb = (int)((map_capacity + CP_BLOCK - 1) / CP_BLOCK);
+    hipLaunchKernelGGL(k_cp_count_active_dev, dim3(nb), dim3(PF_T), 0, st, map_capacity, map_count_dev, w.flags, w.counts);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, w.counts, nb, tgt_count_dev + 1, 0ll, (const long long*)nullptr);
+    hipLaunchKernelGGL(k_gather_active_sub, dim3(nb), dim3(PF_T), 0, st, map_capacity, map_count_dev, w.flags, w.counts, dsratio, map_points,
+                       map_normals, tgt, tgt_normals, tgt_capacity, tgt_count_dev);
+    hipLaunchKernelGGL(k_active_sub_count, dim3(1), dim3(1), 0, st, tgt_count_dev, dsratio, (long long)tgt_capacity);
+    E2E_LAUNCH_CHECK("e2e_pf_active_subsample_dev");
+    return E2E_OK;
+}
+
 int e2e_pf_table(int which, int64_t M, void* workspace, int64_t map_capacity, int H, int W, long long* rows,
                  long long* count_out, void* stream) {
     E2E_REQUIRE(which >= 0 && which <= 2 && M >= 0 && M <= map_capacity && workspace && rows && count_out, E2E_ERR_ARG,

@@ -134,6 +134,11 @@ SIGNATURES = {
     "e2e_head_workspace_floats": [],
     "e2e_head_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp],
     "e2e_icp_workspace_bytes": [],
+    "e2e_icp_state_doubles": [],
+    "e2e_icp_state_init": [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_double, c_fp],
+    "e2e_icp_update": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_fp],
+    "e2e_icp_source_subsample": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
+    "e2e_pf_active_subsample_dev": [c_fp, c_fp, c_fp, c_i64, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_i64, c_fp],
     "e2e_icp_normal_equations": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f32, c_i64, c_fp, c_fp, c_fp],
 }
 _RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats": c_i64,
@@ -141,7 +146,7 @@ _RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats"
             "e2e_knn1_workspace_bytes": c_i64, "e2e_knn1_index_capacity_bytes": c_i64, "e2e_median_workspace_bytes": c_i64,
             "e2e_depth_scale_workspace_bytes": c_i64, "e2e_reduce_workspace_floats": c_i64,
             "e2e_conv2d_wgrad_workspace_floats": c_i64, "e2e_conv2d_wgrad_tuned_workspace_floats": c_i64, "e2e_conv_tuned_workspace_floats": c_i64, "e2e_conv2d_splitk_workspace_floats": c_i64, "e2e_conv2d_bwd_data_workspace_floats": c_i64,
-            "e2e_head_workspace_floats": c_i64, "e2e_icp_workspace_bytes": c_i64, "e2e_aux_workspace_floats": c_i64,
+            "e2e_head_workspace_floats": c_i64, "e2e_icp_workspace_bytes": c_i64, "e2e_icp_state_doubles": c_i64, "e2e_aux_workspace_floats": c_i64,
             "e2e_affine_bwd_workspace_floats": c_i64}
 
 _lib = None

@@ -94,3 +94,94 @@ def frame_to_model(fmap, depth, K, prev_pose, dsratio=4, **kw):
         T, trace = point_to_plane_icp(src, fmap.points[sel], fmap.normals[sel], **kw)
         pose = torch.from_numpy(T @ prev_pose.detach().double().cpu().numpy()).float().to(depth.device)
     return pose, trace
+
+
+class ResidentOdometry:
+    """PointFusion._localize for the driver's resident map WITHOUT a host round trip: source / target selection, the nearest-neighbour
+    index over the targets and the `numiters` Gauss-Newton (icp) or Levenberg-Marquardt (gradicp) iterations are a fixed sequence of
+    launches over buffers allocated once -- sizes that depend on the map (live points, active points, targets) are device data -- so a
+    keyframe's odometry can sit inside the captured map-update graph (RefineStepPlan.update_map_odom).  Same arithmetic as
+    frame_to_model / point_to_plane_icp above (which remain for ad-hoc clouds and as the cross-check) with the 6x6 solve, the se(3)
+    exponential and the damping update in the e2e_icp_update kernel instead of numpy.
+
+    Requires a live frame whose selected pixels all have depth (network predictions 1 / disp do); a hole raises `status`, read by
+    check() together with the target-capacity overflow flag wherever the host synchronises anyway."""
+
+    def __init__(self, fmap, dsratio=4, numiters=20, mode="gradicp", damp=1e-8, dist_thresh=None, lambda_max=2.0, B=1.0, B2=1.0, nu=200.0,
+                 target_capacity=None):
+        if mode not in ("icp", "gradicp"):
+            raise ValueError(f"unknown odometry mode {mode}")
+        self.map, self.ds, self.numiters, self.mode = fmap, int(dsratio), int(numiters), mode
+        self.damp, self.dist_thresh = float(damp), dist_thresh
+        self.lm = (float(lambda_max), float(B), float(B2), float(nu))
+        H, W, dev = fmap.H, fmap.W, fmap.device
+        self.n_src = ((H + self.ds - 1) // self.ds) * ((W + self.ds - 1) // self.ds)
+        # active points are map points that project into ONE frame: a few per pixel at most
+        self.tcap = int(target_capacity or min(fmap.cap, 8 * H * W) // self.ds + 1)
+        f = dict(device=dev, dtype=torch.float32)
+        lib = L.load()
+        self.Vg, self.Ng = torch.empty(1, H, W, 3, **f), torch.empty(1, H, W, 3, **f)
+        self.alpha = torch.empty(1, H, W, **f)
+        self.src, self.cur, self.nxt = (torch.empty(self.n_src, 3, **f) for _ in range(3))
+        self.tgt, self.tgt_n = torch.empty(self.tcap, 3, **f), torch.empty(self.tcap, 3, **f)
+        self.tcount = torch.zeros(3, device=dev, dtype=torch.int64)
+        self.status = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.index = torch.empty(lib.e2e_knn1_index_capacity_bytes(self.n_src, self.tcap), device=dev, dtype=torch.uint8)
+        self.d = torch.empty(self.n_src, **f)
+        self.idx = torch.empty(self.n_src, device=dev, dtype=torch.int64)
+        self.out29 = torch.empty(29, device=dev, dtype=torch.float64)
+        self.ws = torch.empty(lib.e2e_icp_workspace_bytes(), device=dev, dtype=torch.uint8)
+        self.state = torch.zeros(lib.e2e_icp_state_doubles(), device=dev, dtype=torch.float64)
+        self.T32, self.step32 = torch.eye(4, **f), torch.eye(4, **f)
+        self.pose = torch.eye(4, **f)                       # the result: live pose (4,4), rewritten by every run()
+        from .ops import fusion_alpha_den
+        self._alpha_den = float(fusion_alpha_den(fmap.sigma))
+
+    def _reduce(self, pts, st):
+        m = self.map
+        L.call("e2e_knn1_index_query_dev", L.ptr(pts), self.n_src, self.tcap, self.n_src, L.ptr(self.index), L.ptr(self.d), L.ptr(self.idx), st)
+        L.call("e2e_icp_normal_equations", L.ptr(pts), L.ptr(self.tgt), L.ptr(self.tgt_n), L.ptr(self.idx), L.ptr(self.d),
+               -1.0 if self.dist_thresh is None else float(self.dist_thresh), self.n_src, L.ptr(self.out29), L.ptr(self.ws), st)
+
+    def run(self, depth, K, prev_pose):
+        """depth (H,W) of the live frame, K (4,4), prev_pose (4,4): contiguous device tensors (resident buffers when this is captured).
+        Leaves the estimated live pose in self.pose and returns it.  No host synchronisation, no allocation."""
+        m, st = self.map, L.stream()
+        H, W = m.H, m.W
+        for n, t in (("depth", depth), ("K", K), ("prev_pose", prev_pose)):
+            if not L.dev(t, n).is_contiguous():
+                raise ValueError(f"ResidentOdometry.run: {n} must be contiguous")
+        # the live frame placed with the PREVIOUS pose (initial guess), and the map points active in that view
+        L.call("e2e_vertex_normal_maps", L.ptr(depth), L.ptr(K), L.ptr(prev_pose), self._alpha_den, None, None, L.ptr(self.Vg), L.ptr(self.Ng),
+               L.ptr(self.alpha), 1, H, W, st)
+        L.call("e2e_pf_associate_dev", L.ptr(m.points), L.ptr(m.normals), L.ptr(m.ccounts), L.ptr(m.count), L.ptr(K), L.ptr(prev_pose),
+               L.ptr(self.Vg), L.ptr(self.Ng), m.dist_th, m.dot_th, L.ptr(m.ws), m.cap, H, W, st)
+        L.call("e2e_pf_active_subsample_dev", L.ptr(m.points), L.ptr(m.normals), L.ptr(m.count), m.cap, L.ptr(m.ws), H, W, self.ds,
+               L.ptr(self.tgt), L.ptr(self.tgt_n), L.ptr(self.tcount), self.tcap, st)
+        L.call("e2e_icp_source_subsample", L.ptr(self.Vg), L.ptr(depth), H, W, self.ds, L.ptr(self.src), L.ptr(self.status), st)
+        L.call("e2e_knn1_index_build_dev", L.ptr(self.tgt), L.ptr(self.tcount), self.tcap, self.n_src, L.ptr(self.index), st)
+        L.call("e2e_icp_state_init", L.ptr(self.state), L.ptr(self.T32), L.ptr(self.step32), L.ptr(prev_pose), L.ptr(self.pose), self.damp, st)
+        mode = 1 if self.mode == "gradicp" else 0
+        for _ in range(self.numiters):
+            L.call("e2e_transform_points", L.ptr(self.src), L.ptr(self.T32), L.ptr(self.cur), self.n_src, 0, st)
+            self._reduce(self.cur, st)
+            L.call("e2e_icp_update", L.ptr(self.out29), L.ptr(self.state), L.ptr(self.T32), L.ptr(self.step32), L.ptr(prev_pose), L.ptr(self.pose),
+                   mode, 0, *self.lm, st)
+            if mode == 1:
+                L.call("e2e_transform_points", L.ptr(self.cur), L.ptr(self.step32), L.ptr(self.nxt), self.n_src, 0, st)
+                self._reduce(self.nxt, st)
+                L.call("e2e_icp_update", L.ptr(self.out29), L.ptr(self.state), L.ptr(self.T32), L.ptr(self.step32), L.ptr(prev_pose), L.ptr(self.pose),
+                       mode, 1, *self.lm, st)
+        m._assoc_M = None
+        return self.pose
+
+    def check(self):
+        """Host read (one sync) of the two error flags of all runs so far; raises if either fired.  Returns (iterations done by the last run,
+        its trace [(inliers, sum r^2)], targets, active points)."""
+        st, tc, status = self.state.cpu(), self.tcount.cpu(), int(self.status.item())
+        if status:
+            raise RuntimeError("resident odometry: a selected pixel of the live frame had no depth (use icp.frame_to_model for depth maps with holes)")
+        if int(tc[2]):
+            raise RuntimeError(f"resident odometry: more than {self.tcap} target points; raise target_capacity")
+        it = int(st[25])
+        return it, [(int(st[32 + 2 * k]), float(st[33 + 2 * k])) for k in range(min(it, 64))], int(tc[0]), int(tc[1])

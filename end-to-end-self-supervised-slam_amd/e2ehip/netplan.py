@@ -48,6 +48,11 @@ class Buf:
         return self.t.permute(0, 3, 1, 2)
 
 
+def _at(t, slot):
+    """Pointer to a batch buffer, or to image `slot` of it."""
+    return L.ptr(t if slot is None else t[slot])
+
+
 def _sink_of(p):
     s = getattr(p, "_e2e_grad_sink", None)
     if s is None:                                    # no flat bucket (plain torch optimiser): a private gradient tensor
@@ -86,7 +91,8 @@ class _Conv:
                 self.scale = (w / torch.sqrt(rv + eps)).contiguous()
                 self.shift = (b - rm * self.scale).contiguous()
         lib = L.load()
-        n = lib.e2e_conv2d_splitk_workspace_floats(B * self.Ho * self.Wo, self.Cout, self.KH * self.KW * self.Cin)
+        # (a forward of ONE batch slot -- NetPlan.forward_one -- picks its own K split: sized for the larger of the two)
+        n = max(lib.e2e_conv2d_splitk_workspace_floats(b * self.Ho * self.Wo, self.Cout, self.KH * self.KW * self.Cin) for b in {B, 1})
         self.ws_f = torch.zeros(n, device=dev, dtype=_f32) if n else None           # zeroed once: its head holds the stream-K hand-off flags
         self.pp = pad if self.pm == 1 else 0
         self.direct = self.pp == 0 and up == 1 and src1 is None
@@ -105,10 +111,12 @@ class _Conv:
         return [self.weight.data_ptr(), self.wf.data_ptr(), self.wb.data_ptr() if self.wb is not None else 0, self.Cout, self.Cin, self.KH, self.KW,
                 self.ldf, self.ldb, self.scale.data_ptr() if (self.scale is not None and self.wb is not None) else 0]
 
-    def fwd(self, plan, st):
+    def fwd(self, plan, st, slot=None):
+        """slot None: the whole batch; an int: that image of the batch alone (B = 1 launch on the slot's part of every buffer)."""
         s = self
-        L.call("e2e_conv2d_fwd", L.ptr(s.src0.t), L.ptr(s.src1.t) if s.src1 is not None else None, s.C1, s.up, L.ptr(s.wf), s.ldf, L.ptr(s.scale),
-               L.ptr(s.shift if s.bias is None else s.bias), L.ptr(s.res.t) if s.res is not None else None, L.ptr(s.out.t), s.src0.B, s.Hs, s.Ws, s.Cin,
+        L.call("e2e_conv2d_fwd", _at(s.src0.t, slot), _at(s.src1.t, slot) if s.src1 is not None else None, s.C1, s.up, L.ptr(s.wf), s.ldf, L.ptr(s.scale),
+               L.ptr(s.shift if s.bias is None else s.bias), _at(s.res.t, slot) if s.res is not None else None, _at(s.out.t, slot),
+               s.src0.B if slot is None else 1, s.Hs, s.Ws, s.Cin,
                s.Cout, s.KH, s.KW, s.stride, s.pad, s.pm, s.act, float(s.isub), float(s.imul), L.ptr(s.ws_f), st)
 
     def bwd(self, plan, st):
@@ -150,9 +158,9 @@ class _Head:
         self.dz = torch.empty_like(self.out.t)
         self.ws = torch.empty(L.load().e2e_head_workspace_floats(), device=plan.dev, dtype=_f32)
 
-    def fwd(self, plan, st):
+    def fwd(self, plan, st, slot=None):
         s = self.src
-        L.call("e2e_head_fwd", L.ptr(s.t), L.ptr(self.weight), L.ptr(self.bias), L.ptr(self.out.t), s.B, s.h, s.w, s.C, self.act, st)
+        L.call("e2e_head_fwd", _at(s.t, slot), L.ptr(self.weight), L.ptr(self.bias), _at(self.out.t, slot), s.B if slot is None else 1, s.h, s.w, s.C, self.act, st)
 
     def bwd(self, plan, st):
         s, n = self.src, self.out.t.numel()
@@ -170,9 +178,9 @@ class _MaxPool:
         self.out = Buf(src.B, (src.h - 1) // 2 + 1, (src.w - 1) // 2 + 1, src.C, plan.dev)
         self.argmax = torch.empty(self.out.t.shape, device=plan.dev, dtype=torch.uint8)      # window position of every maximum, for the backward
 
-    def fwd(self, plan, st):
+    def fwd(self, plan, st, slot=None):
         s = self.src
-        L.call("e2e_maxpool3x3s2_fwd_idx", L.ptr(s.t), L.ptr(self.out.t), L.ptr(self.argmax), s.B, s.h, s.w, s.C, st)
+        L.call("e2e_maxpool3x3s2_fwd_idx", _at(s.t, slot), _at(self.out.t, slot), _at(self.argmax, slot), s.B if slot is None else 1, s.h, s.w, s.C, st)
 
     def bwd(self, plan, st):
         s = self.src
@@ -193,11 +201,12 @@ class _BNAffine:
         self.scale, self.shift, self.rstd = (torch.empty(C, device=plan.dev, dtype=_f32) for _ in range(3))
         self.ws = torch.empty(L.load().e2e_affine_bwd_workspace_floats(C), device=plan.dev, dtype=_f32)
 
-    def fwd(self, plan, st):
+    def fwd(self, plan, st, slot=None):
         b, s = self.bn, self.src
         L.call("e2e_bn_fold", L.ptr(b.weight), L.ptr(b.bias), L.ptr(b.running_mean), L.ptr(b.running_var), float(b.eps), L.ptr(self.scale),
                L.ptr(self.shift), L.ptr(self.rstd), s.C, st)
-        L.call("e2e_affine_fwd", L.ptr(s.t), L.ptr(self.scale), L.ptr(self.shift), None, 0, L.ptr(self.out.t), s.t.numel(), s.C, st)
+        L.call("e2e_affine_fwd", _at(s.t, slot), L.ptr(self.scale), L.ptr(self.shift), None, 0, _at(self.out.t, slot),
+               s.t.numel() if slot is None else s.t[0].numel(), s.C, st)
 
     def bwd(self, plan, st):
         b, s = self.bn, self.src
@@ -376,6 +385,22 @@ class NetPlan:
         for op in self.ops:
             op.fwd(self, st)
         return self.disp.t.view(self.B, 1, self.H, self.W)
+
+    def forward_one(self, slot):
+        """Forward of ONE image of the batch (B = 1 launches on slot `slot` of every buffer); the other slots keep what they hold."""
+        if not 0 <= slot < self.B:
+            raise ValueError("slot out of range")
+        st = L.stream()
+        for op in self.ops:
+            op.fwd(self, st, slot)
+
+    def move_slot(self, src, dst):
+        """Everything a backward pass reads of image `src` -- every layer's activations, the max-pool's argmax -- copied to image `dst`
+        (device-to-device copies).  With the input frame of `src` loaded into `dst` as well, slot `dst` then holds a complete forward pass."""
+        for op in self.ops:
+            op.out.t[dst].copy_(op.out.t[src])
+            if isinstance(op, _MaxPool):
+                op.argmax[dst].copy_(op.argmax[src])
 
     def backward(self, g_disp=None):
         """g_disp (B,1,H,W): gradient of the loss wrt the disparity (None: already in self.disp.g).  Parameter gradients

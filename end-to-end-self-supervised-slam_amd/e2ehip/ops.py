@@ -457,9 +457,10 @@ def median_lower(x):
 
 class _DepthScale(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, disp, median_gt):
+    def forward(ctx, disp, median_gt, elements):
         d = L.dev(disp, "disp").contiguous()
         mg = L.dev(median_gt, "median_gt").reshape(1).contiguous()
+        ctx.elements = elements
         n = d.numel()
         delta, depth = torch.empty_like(d), torch.empty_like(d)
         md = torch.empty(1, device=d.device, dtype=torch.float32)
@@ -477,14 +478,20 @@ class _DepthScale(torch.autograd.Function):
         delta, mg, md, ws = ctx.saved_tensors
         g = g_depth.contiguous()
         g_disp = torch.empty_like(delta)
-        L.call("e2e_depth_scale_bwd", L.ptr(g), L.ptr(delta), L.ptr(mg), L.ptr(md), L.ptr(g_disp), L.ptr(ws), delta.numel(), L.stream())
-        return g_disp, None
+        el = ctx.elements
+        L.call("e2e_depth_scale_bwd_at", L.ptr(g), L.ptr(delta), L.ptr(mg), L.ptr(md), L.ptr(el), 0 if el is None else int(el.numel()), L.ptr(g_disp),
+               L.ptr(ws), delta.numel(), L.stream())
+        return g_disp, None, None
 
 
-def depth_from_disp_median_scaled(disp, median_gt):
+def depth_from_disp_median_scaled(disp, median_gt, median_elements=None):
     """disp (F,1,H,W) of the keyframe pair -> (depth = (median_gt / median(1/disp)) / disp, unscaled 1/disp, ratio).
-    The ratio stays inside the autograd graph exactly as in online_adaption.py:292-298 (the in-place `*= ratio`)."""
-    return _DepthScale.apply(disp, median_gt)
+    The ratio stays inside the autograd graph exactly as in online_adaption.py:292-298 (the in-place `*= ratio`): its gradient is shared
+    by the elements that hold the median value, as torch.median(x) differentiates.  median_elements (device int32 indices): name those
+    elements instead (parity tests: the choice among near-tied values belongs to the evaluation, e2e_depth_scale_bwd_at)."""
+    if median_elements is not None and (median_elements.dtype != torch.int32 or not median_elements.is_cuda):
+        raise TypeError("median_elements: a device int32 tensor of flat indices")
+    return _DepthScale.apply(disp, median_gt, median_elements)
 
 
 class _FixedScale(torch.autograd.Function):

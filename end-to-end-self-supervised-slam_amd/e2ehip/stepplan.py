@@ -117,6 +117,18 @@ class RefineStepPlan:
         L.call("e2e_depth_scale_fwd", L.ptr(disp), L.ptr(self.median_gt), L.ptr(self.delta), L.ptr(self.depth), L.ptr(self.md), L.ptr(self.ratio),
                L.ptr(self.ws_scale), disp.numel(), st)
 
+    def _forward_new_target(self):
+        """First forward of a keyframe whose SOURCE frame was the previous keyframe's target: the map-update forward of that keyframe
+        (predict_depths, online_adaption.py:329-345) ran this very frame through these very weights -- no optimiser step lies between it and
+        the first forward of the next keyframe (:281) -- so its activations are moved from batch slot 1 to slot 0 and only the new
+        target frame goes through the network (1/8 of all forward work of a keyframe; the reference computes both frames again)."""
+        st = L.stream()
+        self.net.move_slot(1, 0)
+        self.net.forward_one(1)
+        disp = self.net.disp.t.view(2, 1, self.H, self.W)
+        L.call("e2e_depth_scale_fwd", L.ptr(disp), L.ptr(self.median_gt), L.ptr(self.delta), L.ptr(self.depth), L.ptr(self.md), L.ptr(self.ratio),
+               L.ptr(self.ws_scale), disp.numel(), st)
+
     def _loss3d(self, index, warm=False):
         """online_adaption.py:457-471 + :638-645: the target frame's cloud in world coordinates (its pose), transformed AGAIN by T
         (reference quirk), pulled to its nearest neighbours in the detached global map."""
@@ -154,11 +166,16 @@ class RefineStepPlan:
         self.net.refresh_layouts()
 
     # ---- public -----------------------------------------------------------------------------------------------------------
-    def step(self, first_step, knn_index=None):
+    def step(self, first_step, knn_index=None, source_forward_is_current=False):
         """One refinement step on the loaded pair.  first_step: stash 1/disp BEFORE scaling as the regulariser's reference
-        (online_adaption.py:284-285).  knn_index: e2ehip.ops.KnnIndex over the global map, or None on the first keyframe."""
+        (online_adaption.py:284-285).  knn_index: e2ehip.ops.KnnIndex over the global map, or None on the first keyframe.
+        source_forward_is_current: batch slot 1 holds a forward pass of the frame that is now the SOURCE, made with the current weights
+        (the caller's promise: SLAM.refinement keeps track) -- see _forward_new_target."""
         use_3d = knn_index is not None
-        self._run("fwd", self._forward)
+        if source_forward_is_current:
+            self._run("fwd_new_target", self._forward_new_target)
+        else:
+            self._run("fwd", self._forward)
         if first_step and self.reg:
             self.init.copy_(self.delta)
         # the 3-D loss against a RESIDENT index (e2ehip.fusionmap: one buffer per run, map size on the device) has constant launch

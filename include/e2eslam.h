@@ -249,6 +249,13 @@ int e2e_pf_associate_dev(const float* map_points, const float* map_normals, cons
                          const long long* map_count_dev, const float* K, const float* pose, const float* Vg,
                          const float* Ng, float dist_th, float dot_th, void* workspace, int64_t map_capacity,
                          int H, int W, void* stream);
+/* Target cloud of the odometry: the map points the last e2e_pf_associate[_dev] found ACTIVE (find_active_map_points against
+ * the previous frame, online_adaption.py:362 through PointFusion._localize), every dsratio-th of them in ascending map order
+ * (gradslam downsample_pointclouds), gathered with their normals.  tgt_count_dev: int64[3] {targets written, active points,
+ * sticky overflow flag (more targets than tgt_capacity)} -- device data like the map size. */
+int e2e_pf_active_subsample_dev(const float* map_points, const float* map_normals, const long long* map_count_dev,
+                                int64_t map_capacity, void* workspace, int H, int W, int dsratio, float* tgt,
+                                float* tgt_normals, long long* tgt_count_dev, int64_t tgt_capacity, void* stream);
 int e2e_pf_fuse_append_dev(float* map_points, float* map_normals, float* map_colors, float* map_ccounts,
                            long long* map_count_dev, int64_t map_capacity, const float* depth, const float* Vg,
                            const float* Ng, const float* rgb, const float* alpha, void* workspace, int H, int W,
@@ -573,6 +580,31 @@ int64_t e2e_icp_workspace_bytes(void);
 int e2e_icp_normal_equations(const float* src, const float* tgt, const float* tgt_normals,
                              const long long* idx, const float* dists, float dist_thresh, int64_t n,
                              double* out29, void* workspace, void* stream);
+
+/* The rest of an odometry iteration ON THE DEVICE (gradslam odometry providers "icp" / "gradicp" behind PointFusion.step,
+ * online_adaption.py:111-122,362; configs/config.yaml:30-35 ships odom: gradicp): solve (A^T A + lambda I) xi = A^T b, the
+ * se(3) exponential, GradICP's smooth damping update and T <- exp(.) T, all float64, from the 29 sums of
+ * e2e_icp_normal_equations -- so the numiters iterations of a keyframe are a fixed launch sequence without a host round trip.
+ *   state   : e2e_icp_state_doubles() float64 (T, xi, lambda, trace ...), initialised by e2e_icp_state_init (T = I, lambda = damp)
+ *   T32     : (4,4) float32, the running transform for e2e_transform_points(src -> cur)
+ *   step32  : (4,4) float32, GradICP's trial step for e2e_transform_points(cur -> next)
+ *   pose_out: (4,4) float32 = T . prev_pose after every update (may be NULL)
+ * mode 0 "icp":     phase 0 = solve, T <- exp(xi) T.
+ * mode 1 "gradicp": phase 0 = solve, step32 <- exp(xi), remember err / cnt;  phase 1 (out29 = the reduction at the trial pose):
+ *                   delta = err' / cnt' - err / cnt ; lambda *= 1/lmax + (lmax - 1/lmax) / (1 + B exp(-B2 nu delta)) ;
+ *                   T <- exp(xi / (1 + exp(clip(nu delta, +-60)))) T.
+ * Fewer than 6 inliers stop the iteration for good (later updates leave T alone), as the host loop's `break`. */
+int64_t e2e_icp_state_doubles(void);
+int e2e_icp_state_init(double* state, float* T32, float* step32, const float* prev_pose, float* pose_out,
+                       double damp, void* stream);
+int e2e_icp_update(const double* out29, double* state, float* T32, float* step32, const float* prev_pose,
+                   float* pose_out, int mode, int phase, double lambda_max, double B, double B2, double nu,
+                   void* stream);
+/* Source cloud of the odometry (gradslam downsample_rgbdimages): every dsratio-th pixel in both directions of the live
+ * frame's world vertex map Vg (H,W,3), row-major -> src (ceil(H/ds) * ceil(W/ds), 3).  A selected pixel without depth sets
+ * *status (device int32; the resident path serves network-predicted depths, which are positive everywhere). */
+int e2e_icp_source_subsample(const float* Vg, const float* depth, int H, int W, int dsratio, float* src,
+                             int* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Off-by-default losses: loss value(s) AND the gradient for a unit upstream  */
