@@ -236,6 +236,22 @@ class RefineStepPlan:
         self._run(("map", bool(first), id(fmap)), fn)
         fmap.mark_updated_on_device(index_current=True)
 
+    def update_map_odom(self, fmap, first, odometry):
+        """update_map with the reference's default map step (configs/config.yaml:30 odom: gradicp; online_adaption.py:362 passes
+        prev_frame): the new keyframe's pose comes from frame-to-model odometry against the map, started at the previous keyframe's
+        pose, and the frame is fused with the ESTIMATED pose.  odometry: e2ehip.icp.ResidentOdometry over `fmap` -- source / target
+        selection, index build and its numiters iterations incl. the 6x6 solves are launches over resident buffers, so the whole
+        map step (odometry, fusion, rebuild of the nearest-neighbour index) replays as ONE captured graph.  The estimate is left in
+        odometry.pose (device)."""
+        def fn():
+            if first:
+                fmap.step_resident(self.colors[0], self.depth[0, 0], self.K[0], self.pose_src[0])
+            pose = odometry.run(self.depth[1, 0], self.K[0], self.pose_src[0])
+            fmap.step_resident(self.colors[1], self.depth[1, 0], self.K[0], pose)
+            fmap.knn_index(self.N)
+        self._run(("map_odom", bool(first), id(fmap), id(odometry)), fn)
+        fmap.mark_updated_on_device(index_current=True)
+
     def close(self):
         """Deterministic end of the plan (tests build many; a product process builds one): wait for everything it launched -- current
         stream, capture stream, backward-weight side stream --, destroy the captured graphs and with them their private memory pools,

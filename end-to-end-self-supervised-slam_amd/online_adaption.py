@@ -186,6 +186,8 @@ class SLAM:
         if self.args.DEBUG.print_metrics and self.mean_abs:
             print(torch.tensor(self.mean_abs).mean().item())
         self.map.check_capacity()               # the one host read of the map size (and of its overflow flag) of the whole run
+        if getattr(self, "_odo", None) is not None:
+            self._odo.check()                   # ... and of the resident odometry's error flags
         if edist.world() > 1:                   # end of run: variable-length gather of the per-rank maps
             self.gathered_map = edist.gather_maps(*self.map.live(), dst=0)     # rank 0 receives the maps, every rank their sizes
         return self.map
@@ -313,10 +315,21 @@ class SLAM:
                 self._load_pair(sp, *next_pair)
                 self._preloaded = tuple(next_pair)
             return
-        if next_pair is not None:                   # stream-ordered behind the forward above; the map update reads neither of these buffers
+        # MODEL.odom icp / gradicp (the reference's default, configs/config.yaml:30): frame-to-model odometry from the previous keyframe's
+        # pose inside the same captured map step (e2ehip.icp.ResidentOdometry: no host round trip per iteration); the map is fused with the
+        # ESTIMATED pose and the pose itself, which the reference drops (online_adaption.py:362-363), is kept for the trajectory error
+        odo = self._odometry()
+        sp.update_map_odom(self.map, self.first_iter, odo)
+        self.estimated_poses.append((odo.pose.clone(), self.poses[0, cur]))
+        if next_pair is not None:
             self._load_pair(sp, *next_pair)
             self._preloaded = tuple(next_pair)
-        self._update_map(self.colors[0, prev], self.colors[0, cur], depth, self.poses[0, prev], self.poses[0, cur])
+
+    def _odometry(self):
+        if getattr(self, "_odo", None) is None:
+            from e2ehip.icp import ResidentOdometry
+            self._odo = ResidentOdometry(self.map, dsratio=4, numiters=self.args.MODEL.numiters, mode=self.args.MODEL.odom)
+        return self._odo
 
     def _log_step(self, rec, refine_step, nsteps):
         self.log.append(rec)

@@ -34,6 +34,64 @@ def test_frame_to_model_matches_oracle_and_ground_truth(mode):
     assert np.linalg.norm(poses[0].numpy()[:3, 3] - gt[:3, 3]) > 3e-2
 
 
+@pytest.mark.parametrize("mode", ["icp", "gradicp"])
+def test_resident_odometry_equals_host_loop_and_oracle(mode):
+    """e2ehip.icp.ResidentOdometry (round 4): selection of source / target clouds, the index over the targets and the 20 iterations with
+    the 6x6 solve, the se(3) exponential and GradICP's damping update ON THE DEVICE (e2e_icp_update), no host round trip -- against the
+    host-driven loop of the same kernels (frame_to_model: numpy solve per iteration) and against the CPU oracle: same inlier counts in
+    every iteration, same pose.  Run twice (the second time as a captured graph replay would: same buffers) -> bit-identical."""
+    from e2ehip import icp
+    from e2ehip.fusionmap import FusionMap
+    colors, depths, K, poses = _scene()
+    H, W = depths.shape[1:]
+    st, _ = opf.pointfusion_step(opf.empty_state(), colors[0], depths[0], K, poses[0])
+    P_ref, tr_ref = oicp.frame_to_model(st["points"], st["normals"], depths[1], K, poses[0], mode=mode)
+    fm = FusionMap(3 * H * W, H, W, DEV)
+    fm.load_state(st["points"].to(DEV), st["normals"].to(DEV), st["colors"].to(DEV), st["ccounts"].to(DEV))
+    d1, Kd, p0 = depths[1].to(DEV).contiguous(), K.to(DEV).contiguous(), poses[0].to(DEV).contiguous()
+    P_host, tr_host = icp.frame_to_model(fm, d1, Kd, p0, mode=mode)
+    odo = icp.ResidentOdometry(fm, dsratio=4, numiters=20, mode=mode)
+    P1 = odo.run(d1, Kd, p0).clone()
+    its, tr, ntgt, nact = odo.check()
+    assert its == len(tr_host) == len(tr_ref) and ntgt == (nact + 3) // 4
+    assert [c for c, _ in tr] == [c for c, _ in tr_host] == [c for c, _ in tr_ref]
+    np.testing.assert_allclose([e for _, e in tr], [e for _, e in tr_host], rtol=1e-6)
+    np.testing.assert_allclose(P1.cpu().numpy(), P_host.cpu().numpy(), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(P1.cpu().numpy(), P_ref, atol=2e-5, rtol=0)
+    P2 = odo.run(d1, Kd, p0)
+    assert torch.equal(P1, P2)
+    # a hole under a selected pixel is reported, not silently mis-registered
+    d_bad = d1.clone()
+    d_bad[0, 0] = 0.0
+    odo.run(d_bad, Kd, p0)
+    with pytest.raises(RuntimeError, match="no depth"):
+        odo.check()
+
+
+def test_driver_gradicp_runs_resident_and_reports_ate():
+    """configs/config.yaml:30 (odom: gradicp) through the driver's launch plan: the map step with odometry is one captured graph
+    (RefineStepPlan.update_map_odom); the estimated poses stay on the device until the trajectory error is asked for."""
+    from e2ehip.synthetic import make_sequence
+    from online_adaption import SLAM, default_config
+    from oracle import depthnet
+    cfg = default_config(96, 128, 5)
+    cfg.MODEL.odom = "gradicp"
+    cfg.DEMO.frame_threshold = 0.0
+    cfg.DEBUG.print_metrics = False
+    seq = make_sequence(5, 96, 128, seed=3, step=0.03, noise=0.0, scene="corner")
+    sd = depthnet.random_state_dict(0)
+    sd["decoder.decoder.10.conv.weight"] = sd["decoder.decoder.10.conv.weight"] * 40.0
+    drv = SLAM(cfg, sequence=seq, state_dict=sd)
+    drv.main()
+    assert len(drv.estimated_poses) == 4 and all(p.is_cuda for p, _ in drv.estimated_poses)
+    assert any(k[0] == "map_odom" for k in drv.step_plan._graphs if isinstance(k, tuple))
+    ate = drv.absolute_trajectory_error()
+    assert np.isfinite(ate) and ate < 0.25                   # random-weight depths: plumbing, not accuracy
+    its, tr, ntgt, nact = drv._odo.check()
+    assert its >= 1 and ntgt > 100
+    drv.close()
+
+
 def test_normal_equations_kernel_vs_numpy():
     from e2ehip import _lib as L
     from e2ehip import ops
