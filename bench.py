@@ -306,6 +306,41 @@ def seq_bench(a, rank, world, dev):
                                      "method": f"{RUN} back-to-back launches per captured graph between one event pair, trimmed mean of 30 replays"}
         roof["kernel_time_ms_per_keyframe"] = {n: round(r["ms"], 4) for n, r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:16]}
 
+    # ---- odometry against the oracle on the SAME inputs (outside the timed region; --odom icp | gradicp) ------------------
+    # "ATE vs reference": for a few more keyframes the inputs of the frame-to-model odometry (map before the step, predicted depth, previous
+    # pose) are snapshotted, the oracle (oracle/icp.py on the host cores) registers the same frame against the same map, and both poses
+    # are scored against the dataset pose -- two trajectory errors over one prefix, plus the largest difference between the two estimates
+    odom_parity = None
+    if a.odom != "gt" and world == 1 and not a.no_cpu_baseline:
+        from oracle import icp as oicp
+        rows = []
+        for _ in range(3):
+            if state["i"] >= len(sched):
+                slam.reset_map()
+                state["i"], state["passes"] = 0, state["passes"] + 1
+            prev, cur = sched[state["i"]]
+            pts, nrm = (t.clone().cpu() for t in slam.map.live()[:2]) if not slam.first_iter else (None, None)
+            nxt = sched[state["i"] + 1] if state["i"] + 1 < len(sched) else None
+            slam.refinement(prev, cur, next_pair=nxt)
+            slam.first_iter = False
+            state["i"] += 1
+            if pts is None:
+                continue
+            torch.cuda.synchronize(dev)
+            depth = slam.step_plan.depth[1, 0].cpu()
+            est, gt_pose = slam.estimated_poses[-1][0].cpu().double().numpy(), slam.poses[0, cur].cpu().double().numpy()
+            t_o = time.perf_counter()
+            ref, _ = oicp.frame_to_model(pts, nrm, depth, slam.intrinsics[0, 0].cpu(), slam.poses[0, prev].cpu(), mode=a.odom, numiters=cfg.MODEL.numiters)
+            rows.append({"keyframe": state["i"], "map_points": int(pts.shape[0]), "err_gpu_m": float(((est[:3, 3] - gt_pose[:3, 3]) ** 2).sum() ** 0.5),
+                         "err_oracle_m": float(((ref[:3, 3] - gt_pose[:3, 3]) ** 2).sum() ** 0.5), "max_abs_pose_diff": float(abs(est - ref).max()),
+                         "oracle_seconds": time.perf_counter() - t_o})
+        if rows:
+            rms = lambda k: float((sum(r[k] ** 2 for r in rows) / len(rows)) ** 0.5)
+            odom_parity = {"keyframes": rows, "ate_m_gpu": rms("err_gpu_m"), "ate_m_oracle": rms("err_oracle_m"),
+                           "max_abs_pose_diff": max(r["max_abs_pose_diff"] for r in rows),
+                           "note": "same inputs on both sides (map before the step, the GPU's predicted depth, previous dataset pose): oracle/icp.py frame_to_model "
+                                   "on the host vs e2ehip.icp.ResidentOdometry inside the captured map step; errors against the dataset pose"}
+
     # ---- end of run: per-rank map sizes and the map gather (outside the timed region) ---------------------------------
     sizes, gathered = [map_points], map_points
     if world > 1:
@@ -334,6 +369,8 @@ def seq_bench(a, rank, world, dev):
             out["value"] = None
             out["error"] = "replicas diverged: parameter checksums differ between ranks"
         out.update(roof)
+        if odom_parity is not None:
+            out["odometry_vs_oracle"] = odom_parity
         out["source_stamp"] = source_stamp()
         # the default timed region (20 steps from keyframe 3, a small map) reads faster than a whole pass of the 60-frame sequence: the
         # whole-pass figure travels with this line, with the build it was measured on (tools/evidence.sh runs it first)

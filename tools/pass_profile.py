@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--probe", default="3,15,30,45,58", help="keyframes (1-based) whose entry points are event-timed in a SECOND pass over the same schedule")
     ap.add_argument("--seq-len", type=int, default=60)
+    ap.add_argument("--gc", default="default", choices=["default", "freeze", "off"], help="Python's cyclic collector during the passes")
     a = ap.parse_args()
     import torch
     from e2ehip.profile import KernelTimer
@@ -41,6 +42,25 @@ def main():
     slam.first_iter = True
     sched = slam.keyframe_schedule()
     probes = {int(x) for x in a.probe.split(",") if x}
+    # where a slow keyframe comes from: the device time between two events around it (GPU-side work only) next to the wall time, and the
+    # time the host spent inside Python's cyclic garbage collector during it (a gen-2 collection scans every live object of the process:
+    # tens of milliseconds with a network, plans and graphs alive -- and the GPU idles meanwhile: a keyframe is 4 graph replays the host issues)
+    import gc
+    gc_log = {"t0": 0.0, "spent": 0.0, "events": []}
+
+    def gc_cb(phase, info):
+        if phase == "start":
+            gc_log["t0"] = time.perf_counter()
+        else:
+            dt = time.perf_counter() - gc_log["t0"]
+            gc_log["spent"] += dt
+            gc_log["events"].append((info["generation"], 1e3 * dt))
+    gc.callbacks.append(gc_cb)
+    if a.gc == "freeze":
+        gc.collect()
+        gc.freeze()
+    elif a.gc == "off":
+        gc.disable()
     print(f"# {bench.source_stamp()}  pass profile, {len(sched)} keyframes, 3 steps each")
     for p in range(2):
         if p:
@@ -50,6 +70,9 @@ def main():
             nxt = sched[i + 1] if i + 1 < len(sched) else None
             m_before = int(slam.map.count[0])
             torch.cuda.synchronize(dev)
+            gc_log["spent"], gc_log["events"] = 0.0, []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             t0 = time.perf_counter()
             if p == 1 and (i + 1) in probes:
                 with KernelTimer() as kt:
@@ -61,9 +84,12 @@ def main():
                 print(f"keyframe {i + 1:3d}  map {m_before:9d}  kernels {tot:7.3f} ms  " + "  ".join(f"{n.replace('e2e_', '')} {r['ms']:.3f}/{r['calls']}" for n, r in sorted(grow.items())))
             else:
                 slam.refinement(*pair, max_steps=3, next_pair=nxt)
+                e1.record()
                 torch.cuda.synchronize(dev)
                 if p == 0:
-                    print(f"keyframe {i + 1:3d}  map {m_before:9d}  {1e3 * (time.perf_counter() - t0):7.3f} ms")
+                    wall = 1e3 * (time.perf_counter() - t0)
+                    gcs = "" if not gc_log["events"] else "  gc " + " ".join(f"gen{g}:{ms:.2f}ms" for g, ms in gc_log["events"])
+                    print(f"keyframe {i + 1:3d}  map {m_before:9d}  wall {wall:7.3f} ms  device {e0.elapsed_time(e1):7.3f} ms{gcs}")
             slam.first_iter = False
     sys.stdout.flush()
 
