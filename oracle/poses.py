@@ -1,5 +1,8 @@
 """CPU restatement of the 4x4 pose helpers on the path.  TEST INFRASTRUCTURE ONLY.
-Parity: PINNED by tests/golden/g6 (captured from the reference's utils/training_utils.py)."""
+Parity: PINNED by tests/golden/g6 (captured from the reference's utils/training_utils.py) and by the one known answer the reference holds
+for the loader's frame-to-frame `transforms` (pose_checker.py:57-82: T_12 = [R1^T R2 | R1^T (t2 - t1)] "should match Transform 2"):
+tests/test_host_utils.py::test_transforms_match_the_pose_checker_closed_form checks this function, the product's
+utils.training_utils.torch_poses_to_transforms and the product's ICL loader against that closed form."""
 import torch
 
 

@@ -302,7 +302,11 @@ def test_launch_plan_equals_autograd_path_and_graph_replay_is_exact():
         assert torch.equal(sd_g[k], sd_e[k]), k
     # plan vs autograd: identical kernels; multi-consumer gradients are accumulated in a different order and the 3-D loss is a
     # masked mean instead of a mean over gathered rows -> agreement to a few fp32 ulps of each quantity
-    np.testing.assert_allclose(log_g.numpy(), log_a.numpy(), rtol=2e-5, atol=1e-7)
+    # (columns 8-10 are a1 / a2 / a3: FRACTIONS OF PIXELS under a threshold -- a depth that differs in its last bit moves a pixel across
+    # it, one pixel of 64 x 96 is 1.6e-4)
+    cont = [c for c in range(log_g.shape[1]) if c not in (8, 9, 10)]
+    np.testing.assert_allclose(log_g[:, cont].numpy(), log_a[:, cont].numpy(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(log_g[:, 8:11].numpy(), log_a[:, 8:11].numpy(), rtol=0, atol=2.5 / (64 * 96))
     assert map_g.shape == map_a.shape
     torch.testing.assert_close(map_g, map_a, rtol=5e-5, atol=5e-6)     # the networks are up to 2 Adam steps of 1e-5 apart (below)
     for k in sd_g:
