@@ -137,9 +137,15 @@ class ResidentOdometry:
         from .ops import fusion_alpha_den
         self._alpha_den = float(fusion_alpha_den(fmap.sigma))
 
-    def _reduce(self, pts, st):
-        m = self.map
-        L.call("e2e_knn1_index_query_dev", L.ptr(pts), self.n_src, self.tcap, self.n_src, L.ptr(self.index), L.ptr(self.d), L.ptr(self.idx), st)
+    def _reduce(self, pts, st, warm):
+        # from the second search of a keyframe on, the previous search's neighbours (same source points, moved by one small step; same
+        # targets) bound the search from the start: a lane then visits the few cells inside that ball instead of walking three shells of a
+        # sparse grid -- with 19 200 queries there are too few waves to hide that walk's latency (86 + 72 us per cold search, 40 per keyframe)
+        if warm:
+            L.call("e2e_knn1_index_query_dev_image_warm", L.ptr(pts), self.n_src, 0, L.ptr(self.tgt), L.ptr(self.idx), self.tcap, self.n_src,
+                   L.ptr(self.index), L.ptr(self.d), L.ptr(self.idx), st)
+        else:
+            L.call("e2e_knn1_index_query_dev", L.ptr(pts), self.n_src, self.tcap, self.n_src, L.ptr(self.index), L.ptr(self.d), L.ptr(self.idx), st)
         L.call("e2e_icp_normal_equations", L.ptr(pts), L.ptr(self.tgt), L.ptr(self.tgt_n), L.ptr(self.idx), L.ptr(self.d),
                -1.0 if self.dist_thresh is None else float(self.dist_thresh), self.n_src, L.ptr(self.out29), L.ptr(self.ws), st)
 
@@ -162,14 +168,14 @@ class ResidentOdometry:
         L.call("e2e_knn1_index_build_dev", L.ptr(self.tgt), L.ptr(self.tcount), self.tcap, self.n_src, L.ptr(self.index), st)
         L.call("e2e_icp_state_init", L.ptr(self.state), L.ptr(self.T32), L.ptr(self.step32), L.ptr(prev_pose), L.ptr(self.pose), self.damp, st)
         mode = 1 if self.mode == "gradicp" else 0
-        for _ in range(self.numiters):
+        for it in range(self.numiters):
             L.call("e2e_transform_points", L.ptr(self.src), L.ptr(self.T32), L.ptr(self.cur), self.n_src, 0, st)
-            self._reduce(self.cur, st)
+            self._reduce(self.cur, st, warm=it > 0)
             L.call("e2e_icp_update", L.ptr(self.out29), L.ptr(self.state), L.ptr(self.T32), L.ptr(self.step32), L.ptr(prev_pose), L.ptr(self.pose),
                    mode, 0, *self.lm, st)
             if mode == 1:
                 L.call("e2e_transform_points", L.ptr(self.cur), L.ptr(self.step32), L.ptr(self.nxt), self.n_src, 0, st)
-                self._reduce(self.nxt, st)
+                self._reduce(self.nxt, st, warm=True)
                 L.call("e2e_icp_update", L.ptr(self.out29), L.ptr(self.state), L.ptr(self.T32), L.ptr(self.step32), L.ptr(prev_pose), L.ptr(self.pose),
                        mode, 1, *self.lm, st)
         m._assoc_M = None
