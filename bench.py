@@ -224,6 +224,11 @@ def seq_bench(a, rank, world, dev):
         el = float(tt.item())
     map_points = int(slam.map.M)
     ate = slam.absolute_trajectory_error() if a.odom != "gt" else None
+    odo_info = None
+    if a.odom != "gt" and getattr(slam, "_odo", None) is not None:
+        its, _, ntgt, nact = slam._odo.check()
+        odo_info = {"iterations_last_keyframe": its, "target_points": ntgt, "active_map_points": nact, "source_points": slam._odo.n_src,
+                    "grid_cells_per_axis": slam._odo.cells}
     replicas_identical = True
     if world > 1:                                       # data parallel: the shared depth network must be bit-identical on every rank
         cs = slam.optimizer.flat.data.double().sum().reshape(1).to("cpu" if dist.get_backend() == "gloo" else dev)
@@ -361,7 +366,7 @@ def seq_bench(a, rank, world, dev):
                                       + (", one sequence per GPU, 1 all-reduce of the 57.3 MB gradient bucket per step" if world > 1 else ""),
                           "height": H, "width": W, "seq_len": L, "keyframes_per_pass": len(sched), "refinement_steps_per_keyframe": spk, "odom": a.odom,
                           "sequence_passes_started": state["passes"] + 1, "map_points_rank0": map_points, "map_points_per_rank": sizes,
-                          "map_points_gathered": gathered, "ate_m": ate, "replicas_identical": replicas_identical, "keyframes_covered": covered,
+                          "map_points_gathered": gathered, "ate_m": ate, "odometry": odo_info, "replicas_identical": replicas_identical, "keyframes_covered": covered,
                           "network_seed": NET_SEED, "parameter_checksum": float(slam.optimizer.flat.data.double().sum()) if slam.optimizer.flat is not None else None,
                           "same_sequence_on_every_rank": bool(a.same_sequence),
                           "exchange_forced_on_one_rank": world == 1 and edist.data_parallel()}}

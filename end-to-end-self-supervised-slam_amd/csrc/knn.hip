@@ -185,9 +185,10 @@ __global__ __launch_bounds__(KT) void k_grid_bbox(const float* __restrict__ p, i
 }
 
 __global__ __launch_bounds__(BBOX_BLOCKS) void k_grid_setup(GridInfo* gi, const unsigned int* __restrict__ part, int nparts, int gmax,
-                                                            const long long* __restrict__ nptr, long long n_host) {
+                                                            const long long* __restrict__ nptr, long long n_host, int gmax_force) {
     __shared__ unsigned int sh[6][BBOX_BLOCKS / 64];
     if (nptr) gmax = (*nptr >= GRID_BIG_N2) ? GRID_MAX_BIG : GRID_MAX_SMALL;      // the host's rule (grid_max_for) on the device-resident count
+    if (gmax_force > 0) gmax = gmax_force;
     if (threadIdx.x == 0) gi->n_points = (unsigned int)(nptr ? *nptr : n_host);
     for (int c = 0; c < 6; ++c) {
         unsigned int v = (threadIdx.x < nparts) ? part[threadIdx.x * 6 + c] : (c < 3 ? 0xFFFFFFFFu : 0u);
@@ -549,8 +550,9 @@ extern "C" {
 static int knn1_brute(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists, long long* idx, void* workspace, hipStream_t st);
 #define KNN_GRID_MIN_N2 8192      // below this the brute force is already cheap
 
-static int64_t grid_ws_bytes(int64_t n1, int64_t n2, bool big_always = false) {
-    const int64_t nc = big_always ? (int64_t)GRID_MAX_BIG * GRID_MAX_BIG * GRID_MAX_BIG : grid_cells_cap(n2), nb = (nc + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
+static int64_t grid_ws_bytes(int64_t n1, int64_t n2, bool big_always = false, int cells = 0) {
+    const int64_t nc = cells > 0 ? (int64_t)cells * cells * cells : (big_always ? (int64_t)GRID_MAX_BIG * GRID_MAX_BIG * GRID_MAX_BIG : grid_cells_cap(n2)),
+                  nb = (nc + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
     // GridInfo | counts[nc+1] | starts[nc+1] | fill[nc] | bsum[nb] | cell_of[n2] | unresolved[n1] | sorted float4[n2]
     return 256 + 4 * (nc + 1) * 2 + 4 * nc + 4 * (nb + 1) + 4 * 6 * BBOX_BLOCKS + 4 * n2 + 4 * n1 + 64 + 16 * n2;
 }
@@ -571,9 +573,10 @@ struct GridWs {
 };
 
 // carve the workspace: `nq` = number of query slots reserved for the unresolved list
-static GridWs grid_ws(void* workspace, int64_t nq, int64_t n2, bool big_always = false) {
+// cells > 0: a caller-chosen resolution (cells per axis, the *_res entry points) instead of the map-tuned rule
+static GridWs grid_ws(void* workspace, int64_t nq, int64_t n2, bool big_always = false, int cells = 0) {
     GridWs g;
-    g.nc = big_always ? (int64_t)GRID_MAX_BIG * GRID_MAX_BIG * GRID_MAX_BIG : grid_cells_cap(n2);
+    g.nc = cells > 0 ? (int64_t)cells * cells * cells : (big_always ? (int64_t)GRID_MAX_BIG * GRID_MAX_BIG * GRID_MAX_BIG : grid_cells_cap(n2));
     g.nb = (int)((g.nc + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK);
     char* w = (char*)workspace;
     g.gi = (GridInfo*)w; w += 256;
@@ -592,13 +595,13 @@ static GridWs grid_ws(void* workspace, int64_t nq, int64_t n2, bool big_always =
 __global__ void k_grid_reset_unresolved(GridInfo* gi) { gi->n_unresolved = 0; }
 
 // n2: number of reference points, or -- with n2_dev != NULL -- their CAPACITY (the live count is read on the device)
-static void grid_build(const float* p2, int64_t n2, const long long* n2_dev, const GridWs& g, hipStream_t st) {
+static void grid_build(const float* p2, int64_t n2, const long long* n2_dev, const GridWs& g, hipStream_t st, int cells = 0) {
     const int64_t nscan = g.nc + 1;
     const int gp = (int)((n2 + KT - 1) / KT > 2048 ? 2048 : (n2 + KT - 1) / KT);
     hipLaunchKernelGGL(k_grid_init, dim3(2048), dim3(256), 0, st, g.gi, g.counts, g.fill, g.nc);
     const int bb_blocks = gp > BBOX_BLOCKS ? BBOX_BLOCKS : gp;
     hipLaunchKernelGGL(k_grid_bbox, dim3(bb_blocks), dim3(KT), 0, st, p2, n2, n2_dev, g.bbpart);
-    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(BBOX_BLOCKS), 0, st, g.gi, g.bbpart, bb_blocks, grid_max_for(n2), n2_dev, (long long)n2);
+    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(BBOX_BLOCKS), 0, st, g.gi, g.bbpart, bb_blocks, grid_max_for(n2), n2_dev, (long long)n2, cells);
     hipLaunchKernelGGL(k_grid_count, dim3(gp), dim3(KT), 0, st, p2, n2, n2_dev, g.gi, g.cell_of, g.counts);
     hipLaunchKernelGGL(k_scan_blocksum, dim3(g.nb), dim3(KT), 0, st, g.counts, nscan, g.bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, g.bsum, g.nb);
@@ -678,6 +681,36 @@ int e2e_knn1_index_query_dev_image_warm(const float* p1, int64_t n1, int row_len
     hipLaunchKernelGGL(k_grid_reset_unresolved, dim3(1), dim3(1), 0, (hipStream_t)stream, g.gi);
     grid_query(p1, n1, g, dists, idx, (hipStream_t)stream, row_len, ref_points, warm_idx);
     E2E_LAUNCH_CHECK("e2e_knn1_index_query_dev_image_warm");
+    return E2E_OK;
+}
+
+/* The resident index at a caller-chosen resolution (cells per axis, 4 .. 256): the rule above is tuned for 307 200 queries against a
+ * map of 0.25 - 12 M points, a few centimetres off its surface.  Frame-to-model odometry asks 19 200 queries of a sparse target set
+ * (every 4th active point), possibly decimetres away while the pose is still wrong: a lane then walks thousands of empty fine cells
+ * with dependent loads and there are too few waves to hide them; a coarse grid (32 per axis) bounds the walk to a few cells of ~100
+ * points each.  Results are identical at any resolution.  ref_points / warm_idx: both NULL (cold) or both set (warm start). */
+int64_t e2e_knn1_index_capacity_bytes_res(int64_t max_queries, int64_t n2_capacity, int cells_per_axis) {
+    if (max_queries <= 0 || n2_capacity <= 0 || cells_per_axis < 4 || cells_per_axis > GRID_MAX_BIG) return 0;
+    return grid_ws_bytes(max_queries, n2_capacity, true, cells_per_axis);
+}
+
+int e2e_knn1_index_build_dev_res(const float* p2, const long long* n2_dev, int64_t n2_capacity, int64_t max_queries, void* index, int cells_per_axis,
+                                 void* stream) {
+    E2E_REQUIRE(p2 && n2_dev && index && n2_capacity > 0 && n2_capacity < 0xFFFFFFFFll && max_queries > 0 && max_queries < 0xFFFFFFFFll &&
+                cells_per_axis >= 4 && cells_per_axis <= GRID_MAX_BIG, E2E_ERR_ARG, "e2e_knn1_index_build_dev_res: bad argument");
+    grid_build(p2, n2_capacity, n2_dev, grid_ws(index, max_queries, n2_capacity, true, cells_per_axis), (hipStream_t)stream, cells_per_axis);
+    E2E_LAUNCH_CHECK("e2e_knn1_index_build_dev_res");
+    return E2E_OK;
+}
+
+int e2e_knn1_index_query_dev_res(const float* p1, int64_t n1, const float* ref_points, const long long* warm_idx, int64_t n2_capacity,
+                                 int64_t max_queries, void* index, int cells_per_axis, float* dists, long long* idx, void* stream) {
+    E2E_REQUIRE(p1 && index && dists && idx && n1 > 0 && n1 <= max_queries && n2_capacity > 0 && cells_per_axis >= 4 && cells_per_axis <= GRID_MAX_BIG &&
+                ((ref_points == nullptr) == (warm_idx == nullptr)), E2E_ERR_ARG, "e2e_knn1_index_query_dev_res: bad argument");
+    const GridWs g = grid_ws(index, max_queries, n2_capacity, true, cells_per_axis);
+    hipLaunchKernelGGL(k_grid_reset_unresolved, dim3(1), dim3(1), 0, (hipStream_t)stream, g.gi);
+    grid_query(p1, n1, g, dists, idx, (hipStream_t)stream, 0, ref_points, warm_idx);
+    E2E_LAUNCH_CHECK("e2e_knn1_index_query_dev_res");
     return E2E_OK;
 }
 

@@ -65,6 +65,9 @@ SIGNATURES = {
     "e2e_knn1_index_query_dev": [c_fp, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp],
     "e2e_knn1_index_query_dev_image": [c_fp, c_i64, c_int, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp],
     "e2e_knn1_index_query_dev_image_warm": [c_fp, c_i64, c_int, c_fp, c_fp, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp],
+    "e2e_knn1_index_capacity_bytes_res": [c_i64, c_i64, c_int],
+    "e2e_knn1_index_build_dev_res": [c_fp, c_fp, c_i64, c_i64, c_fp, c_int, c_fp],
+    "e2e_knn1_index_query_dev_res": [c_fp, c_i64, c_fp, c_fp, c_i64, c_i64, c_fp, c_int, c_fp, c_fp, c_fp],
     "e2e_knn1_workspace_bytes": [c_i64, c_i64],
     "e2e_knn1_fwd": [c_fp, c_i64, c_fp, c_i64, c_fp, c_fp, c_fp, c_int, c_fp],
     "e2e_knn1_index_build": [c_fp, c_i64, c_i64, c_fp, c_fp],
@@ -143,7 +146,7 @@ SIGNATURES = {
 }
 _RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats": c_i64,
             "e2e_warp_photo_lossgrad_workspace_floats": c_i64, "e2e_pf_workspace_bytes": c_i64,
-            "e2e_knn1_workspace_bytes": c_i64, "e2e_knn1_index_capacity_bytes": c_i64, "e2e_median_workspace_bytes": c_i64,
+            "e2e_knn1_workspace_bytes": c_i64, "e2e_knn1_index_capacity_bytes": c_i64, "e2e_knn1_index_capacity_bytes_res": c_i64, "e2e_median_workspace_bytes": c_i64,
             "e2e_depth_scale_workspace_bytes": c_i64, "e2e_reduce_workspace_floats": c_i64,
             "e2e_conv2d_wgrad_workspace_floats": c_i64, "e2e_conv2d_wgrad_tuned_workspace_floats": c_i64, "e2e_conv_tuned_workspace_floats": c_i64, "e2e_conv2d_splitk_workspace_floats": c_i64, "e2e_conv2d_bwd_data_workspace_floats": c_i64,
             "e2e_head_workspace_floats": c_i64, "e2e_icp_workspace_bytes": c_i64, "e2e_icp_state_doubles": c_i64, "e2e_aux_workspace_floats": c_i64,

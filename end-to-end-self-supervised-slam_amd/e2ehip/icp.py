@@ -108,7 +108,7 @@ class ResidentOdometry:
     check() together with the target-capacity overflow flag wherever the host synchronises anyway."""
 
     def __init__(self, fmap, dsratio=4, numiters=20, mode="gradicp", damp=1e-8, dist_thresh=None, lambda_max=2.0, B=1.0, B2=1.0, nu=200.0,
-                 target_capacity=None):
+                 target_capacity=None, grid_cells=32):
         if mode not in ("icp", "gradicp"):
             raise ValueError(f"unknown odometry mode {mode}")
         self.map, self.ds, self.numiters, self.mode = fmap, int(dsratio), int(numiters), mode
@@ -126,7 +126,9 @@ class ResidentOdometry:
         self.tgt, self.tgt_n = torch.empty(self.tcap, 3, **f), torch.empty(self.tcap, 3, **f)
         self.tcount = torch.zeros(3, device=dev, dtype=torch.int64)
         self.status = torch.zeros(1, device=dev, dtype=torch.int32)
-        self.index = torch.empty(lib.e2e_knn1_index_capacity_bytes(self.n_src, self.tcap), device=dev, dtype=torch.uint8)
+        # a coarse grid: 19 200 queries of a sparse target set, decimetres away while the pose is still wrong (e2e_knn1_index_*_res)
+        self.cells = int(grid_cells)
+        self.index = torch.empty(lib.e2e_knn1_index_capacity_bytes_res(self.n_src, self.tcap, self.cells), device=dev, dtype=torch.uint8)
         self.d = torch.empty(self.n_src, **f)
         self.idx = torch.empty(self.n_src, device=dev, dtype=torch.int64)
         self.out29 = torch.empty(29, device=dev, dtype=torch.float64)
@@ -141,11 +143,8 @@ class ResidentOdometry:
         # from the second search of a keyframe on, the previous search's neighbours (same source points, moved by one small step; same
         # targets) bound the search from the start: a lane then visits the few cells inside that ball instead of walking three shells of a
         # sparse grid -- with 19 200 queries there are too few waves to hide that walk's latency (86 + 72 us per cold search, 40 per keyframe)
-        if warm:
-            L.call("e2e_knn1_index_query_dev_image_warm", L.ptr(pts), self.n_src, 0, L.ptr(self.tgt), L.ptr(self.idx), self.tcap, self.n_src,
-                   L.ptr(self.index), L.ptr(self.d), L.ptr(self.idx), st)
-        else:
-            L.call("e2e_knn1_index_query_dev", L.ptr(pts), self.n_src, self.tcap, self.n_src, L.ptr(self.index), L.ptr(self.d), L.ptr(self.idx), st)
+        L.call("e2e_knn1_index_query_dev_res", L.ptr(pts), self.n_src, L.ptr(self.tgt) if warm else None, L.ptr(self.idx) if warm else None, self.tcap,
+               self.n_src, L.ptr(self.index), self.cells, L.ptr(self.d), L.ptr(self.idx), st)
         L.call("e2e_icp_normal_equations", L.ptr(pts), L.ptr(self.tgt), L.ptr(self.tgt_n), L.ptr(self.idx), L.ptr(self.d),
                -1.0 if self.dist_thresh is None else float(self.dist_thresh), self.n_src, L.ptr(self.out29), L.ptr(self.ws), st)
 
@@ -165,7 +164,7 @@ class ResidentOdometry:
         L.call("e2e_pf_active_subsample_dev", L.ptr(m.points), L.ptr(m.normals), L.ptr(m.count), m.cap, L.ptr(m.ws), H, W, self.ds,
                L.ptr(self.tgt), L.ptr(self.tgt_n), L.ptr(self.tcount), self.tcap, st)
         L.call("e2e_icp_source_subsample", L.ptr(self.Vg), L.ptr(depth), H, W, self.ds, L.ptr(self.src), L.ptr(self.status), st)
-        L.call("e2e_knn1_index_build_dev", L.ptr(self.tgt), L.ptr(self.tcount), self.tcap, self.n_src, L.ptr(self.index), st)
+        L.call("e2e_knn1_index_build_dev_res", L.ptr(self.tgt), L.ptr(self.tcount), self.tcap, self.n_src, L.ptr(self.index), self.cells, st)
         L.call("e2e_icp_state_init", L.ptr(self.state), L.ptr(self.T32), L.ptr(self.step32), L.ptr(prev_pose), L.ptr(self.pose), self.damp, st)
         mode = 1 if self.mode == "gradicp" else 0
         for it in range(self.numiters):

@@ -65,6 +65,11 @@ class RefineStepPlan:
         self.g3 = torch.zeros(1, 1, H, W, **f)
         self.ws_aux = torch.empty(lib.e2e_aux_workspace_floats(), **f)
         self._graphs, self._gstream = {}, None
+        # what the map step reads of the pair it belongs to (frames, both poses), as private copies (stash_map_inputs): the NEXT pair can then
+        # be loaded into the network's input buffers before the map step runs, and its target frame forwarded NEXT TO the map step
+        self.map_rgb = torch.empty(2, H, W, 3, **f)
+        self.map_pose_src, self.map_pose_tgt = (torch.eye(4, **f).reshape(1, 4, 4).clone() for _ in range(2))
+        self._pstream = None
         # tests: device int32 indices (into the stacked (2,1,H,W) predictions) of the elements the CPU evaluation's torch.median holds
         # as the median -- the ratio's gradient then lands on exactly those (e2e_depth_scale_bwd_at) instead of on this evaluation's own
         self.median_elements_override = None
@@ -117,6 +122,34 @@ class RefineStepPlan:
         L.call("e2e_depth_scale_fwd", L.ptr(disp), L.ptr(self.median_gt), L.ptr(self.delta), L.ptr(self.depth), L.ptr(self.md), L.ptr(self.ratio),
                L.ptr(self.ws_scale), disp.numel(), st)
 
+    def stash_map_inputs(self):
+        """Private copies of the loaded pair's frames and poses for the map step that follows (three device-to-device copies)."""
+        self.map_rgb.copy_(self.colors)
+        self.map_pose_src.copy_(self.pose_src)
+        self.map_pose_tgt.copy_(self.pose_tgt)
+
+    def _scale_only(self):
+        """First 'forward' of a keyframe whose two frames already went through the network with the current weights (the source frame in
+        the previous keyframe's map-update forward, the target frame next to that keyframe's map step: update_map(prefetch=True))."""
+        disp = self.net.disp.t.view(2, 1, self.H, self.W)
+        L.call("e2e_depth_scale_fwd", L.ptr(disp), L.ptr(self.median_gt), L.ptr(self.delta), L.ptr(self.depth), L.ptr(self.md), L.ptr(self.ratio),
+               L.ptr(self.ws_scale), disp.numel(), L.stream())
+
+    def _prefetch_fork(self):
+        """Inside the map-step graph: the activations of the old target frame move to slot 0 and the NEW target frame (already in the
+        input buffer) goes through the network on a second stream, concurrently with the map step -- a chain of small latency-bound
+        kernels (association over the map, compaction scans, the index rebuild's atomics) that leaves most of the GPU idle."""
+        cur = torch.cuda.current_stream(self.dev)
+        if self._pstream is None:
+            self._pstream = torch.cuda.Stream(self.dev)
+        self._pstream.wait_stream(cur)
+        with torch.cuda.stream(self._pstream):
+            self.net.move_slot(1, 0)
+            self.net.forward_one(1)
+
+    def _prefetch_join(self):
+        torch.cuda.current_stream(self.dev).wait_stream(self._pstream)
+
     def _forward_new_target(self):
         """First forward of a keyframe whose SOURCE frame was the previous keyframe's target: the map-update forward of that keyframe
         (predict_depths, online_adaption.py:329-345) ran this very frame through these very weights -- no optimiser step lies between it and
@@ -166,13 +199,16 @@ class RefineStepPlan:
         self.net.refresh_layouts()
 
     # ---- public -----------------------------------------------------------------------------------------------------------
-    def step(self, first_step, knn_index=None, source_forward_is_current=False):
+    def step(self, first_step, knn_index=None, source_forward_is_current=False, both_forwards_are_current=False):
         """One refinement step on the loaded pair.  first_step: stash 1/disp BEFORE scaling as the regulariser's reference
         (online_adaption.py:284-285).  knn_index: e2ehip.ops.KnnIndex over the global map, or None on the first keyframe.
         source_forward_is_current: batch slot 1 holds a forward pass of the frame that is now the SOURCE, made with the current weights
-        (the caller's promise: SLAM.refinement keeps track) -- see _forward_new_target."""
+        (the caller's promise: SLAM.refinement keeps track) -- see _forward_new_target.  both_forwards_are_current: both slots do
+        (update_map(prefetch=True) ran the new target next to the map step) -- see _scale_only."""
         use_3d = knn_index is not None
-        if source_forward_is_current:
+        if both_forwards_are_current:
+            self._run("scale_only", self._scale_only)
+        elif source_forward_is_current:
             self._run("fwd_new_target", self._forward_new_target)
         else:
             self._run("fwd", self._forward)
@@ -222,21 +258,26 @@ class RefineStepPlan:
         self._run("fwd", self._forward)
         return self.depth
 
-    def update_map(self, fmap, first):
+    def update_map(self, fmap, first, prefetch=False):
         """The keyframe's PointFusion map step(s) (online_adaption.py:347-363 with the ground-truth poses) and the rebuild of the
-        nearest-neighbour index over the grown map, from the RESIDENT buffers of the loaded pair -- frames, median-scaled depths of the
-        last forward (predict_depths), intrinsics, the two poses -- so that every launch argument is constant and the ~25 launches
-        replay as one captured graph (issued eagerly they left the GPU idle ~8 us per launch: the host cannot run ahead of a replaying
-        graph).  first: the map is empty, the previous keyframe's frame is fused before the new one's."""
+        nearest-neighbour index over the grown map, from RESIDENT buffers -- the stashed frames and poses of the pair (stash_map_inputs),
+        the median-scaled depths of the last forward (predict_depths), the intrinsics -- so that every launch argument is constant and the
+        ~25 launches replay as one captured graph (issued eagerly they left the GPU idle ~8 us per launch: the host cannot run ahead of a
+        replaying graph).  first: the map is empty, the previous keyframe's frame is fused before the new one's.
+        prefetch: the NEXT pair is already loaded (its source frame = this pair's target): forward its target frame concurrently."""
         def fn():
+            if prefetch:
+                self._prefetch_fork()
             if first:
-                fmap.step_resident(self.colors[0], self.depth[0, 0], self.K[0], self.pose_src[0])
-            fmap.step_resident(self.colors[1], self.depth[1, 0], self.K[0], self.pose_tgt[0])
+                fmap.step_resident(self.map_rgb[0], self.depth[0, 0], self.K[0], self.map_pose_src[0])
+            fmap.step_resident(self.map_rgb[1], self.depth[1, 0], self.K[0], self.map_pose_tgt[0])
             fmap.knn_index(self.N)                                  # rebuilt in place from the device-resident point count
-        self._run(("map", bool(first), id(fmap)), fn)
+            if prefetch:
+                self._prefetch_join()
+        self._run(("map", bool(first), id(fmap), bool(prefetch)), fn)
         fmap.mark_updated_on_device(index_current=True)
 
-    def update_map_odom(self, fmap, first, odometry):
+    def update_map_odom(self, fmap, first, odometry, prefetch=False):
         """update_map with the reference's default map step (configs/config.yaml:30 odom: gradicp; online_adaption.py:362 passes
         prev_frame): the new keyframe's pose comes from frame-to-model odometry against the map, started at the previous keyframe's
         pose, and the frame is fused with the ESTIMATED pose.  odometry: e2ehip.icp.ResidentOdometry over `fmap` -- source / target
@@ -244,12 +285,16 @@ class RefineStepPlan:
         map step (odometry, fusion, rebuild of the nearest-neighbour index) replays as ONE captured graph.  The estimate is left in
         odometry.pose (device)."""
         def fn():
+            if prefetch:
+                self._prefetch_fork()
             if first:
-                fmap.step_resident(self.colors[0], self.depth[0, 0], self.K[0], self.pose_src[0])
-            pose = odometry.run(self.depth[1, 0], self.K[0], self.pose_src[0])
-            fmap.step_resident(self.colors[1], self.depth[1, 0], self.K[0], pose)
+                fmap.step_resident(self.map_rgb[0], self.depth[0, 0], self.K[0], self.map_pose_src[0])
+            pose = odometry.run(self.depth[1, 0], self.K[0], self.map_pose_src[0])
+            fmap.step_resident(self.map_rgb[1], self.depth[1, 0], self.K[0], pose)
             fmap.knn_index(self.N)
-        self._run(("map_odom", bool(first), id(fmap), id(odometry)), fn)
+            if prefetch:
+                self._prefetch_join()
+        self._run(("map_odom", bool(first), id(fmap), id(odometry), bool(prefetch)), fn)
         fmap.mark_updated_on_device(index_current=True)
 
     def close(self):
@@ -259,6 +304,8 @@ class RefineStepPlan:
         torch.cuda.current_stream(self.dev).synchronize()
         if self._gstream is not None:
             self._gstream.synchronize()
+        if self._pstream is not None:
+            self._pstream.synchronize()
         self._graphs.clear()
         self.net.close()
         self._closed = True

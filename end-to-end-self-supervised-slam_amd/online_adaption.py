@@ -287,10 +287,10 @@ class SLAM:
         index = self.map.knn_index(self.H * self.W) if use_3d else None     # one grid build per keyframe, three queries
         nsteps = a.OPTIMIZATION.refinement_steps if max_steps is None else min(int(max_steps), a.OPTIMIZATION.refinement_steps)
         for refine_step in range(nsteps):
-            reuse = refine_step == 0 and self.reuse_forward and self._forward_holds is not None and self._forward_holds == prev
+            held = self._forward_holds if (refine_step == 0 and self.reuse_forward and self._forward_holds is not None) else (None, None)
             if self.median_elements is not None:
                 sp.median_elements_override = self.median_elements[self.refinement_steps_done]
-            sp.step(refine_step == 0, index, source_forward_is_current=reuse)
+            sp.step(refine_step == 0, index, source_forward_is_current=held == (None, prev), both_forwards_are_current=held == (prev, cur))
             if self.median_elements_log is not None:
                 self.median_elements_log.append((sp.delta.reshape(-1) == sp.md).nonzero().reshape(-1).to(torch.int32))
             self._forward_holds = None              # Adam stepped
@@ -304,26 +304,28 @@ class SLAM:
                     total = total + a.LOSS.three3d_loss_weight * l3
                 rec = torch.cat([total.reshape(1), lp.reshape(1), lr.reshape(1), sp.ratio.reshape(1), m, l3v.reshape(1)]).cpu()
                 self._log_step(rec, refine_step, nsteps)
-        # map update (online_adaption.py:329-366): one more forward with the refined network, then PointFusion
-        depth = sp.predict_depths()
-        self._forward_holds = cur                   # slot 1: frame `cur` through the refined weights
-        if a.MODEL.odom == "gt":
-            # everything the map step reads sits in the plan's resident buffers (frames, scaled depths, intrinsics, both poses): one
-            # captured graph incl. the rebuild of the nearest-neighbour index; the next pair's inputs are loaded AFTER it
-            sp.update_map(self.map, self.first_iter)
-            if next_pair is not None:
-                self._load_pair(sp, *next_pair)
-                self._preloaded = tuple(next_pair)
-            return
-        # MODEL.odom icp / gradicp (the reference's default, configs/config.yaml:30): frame-to-model odometry from the previous keyframe's
-        # pose inside the same captured map step (e2ehip.icp.ResidentOdometry: no host round trip per iteration); the map is fused with the
-        # ESTIMATED pose and the pose itself, which the reference drops (online_adaption.py:362-363), is kept for the trajectory error
-        odo = self._odometry()
-        sp.update_map_odom(self.map, self.first_iter, odo)
-        self.estimated_poses.append((odo.pose.clone(), self.poses[0, cur]))
+        # map update (online_adaption.py:329-366): one more forward with the refined network, then PointFusion.  Everything the map step
+        # reads sits in resident buffers (stashed frames and poses, scaled depths, intrinsics): one captured graph incl. the rebuild of the
+        # nearest-neighbour index.  The NEXT pair's inputs are loaded before it, and -- its source frame being this pair's target, already
+        # forwarded with the weights the next keyframe starts from -- its target frame goes through the network next to the map step
+        sp.predict_depths()
+        sp.stash_map_inputs()
+        prefetch = False
         if next_pair is not None:
             self._load_pair(sp, *next_pair)
             self._preloaded = tuple(next_pair)
+            prefetch = self.reuse_forward and next_pair[0] == cur
+        if a.MODEL.odom == "gt":
+            sp.update_map(self.map, self.first_iter, prefetch=prefetch)
+        else:
+            # MODEL.odom icp / gradicp (the reference's default, configs/config.yaml:30): frame-to-model odometry from the previous keyframe's
+            # pose inside the same captured map step (e2ehip.icp.ResidentOdometry: no host round trip per iteration); the map is fused with
+            # the ESTIMATED pose and the pose itself, which the reference drops (online_adaption.py:362-363), is kept for the trajectory error
+            odo = self._odometry()
+            sp.update_map_odom(self.map, self.first_iter, odo, prefetch=prefetch)
+            self.estimated_poses.append((odo.pose.clone(), self.poses[0, cur]))
+        # slots of the plan's batch that hold a complete forward pass made with the current weights: (frame in slot 0, frame in slot 1)
+        self._forward_holds = (cur, next_pair[1]) if prefetch else (None, cur)
 
     def _odometry(self):
         if getattr(self, "_odo", None) is None:

@@ -300,6 +300,16 @@ int e2e_knn1_index_build_dev(const float* p2, const long long* n2_dev, int64_t n
                              void* index, void* stream);
 int e2e_knn1_index_query_dev(const float* p1, int64_t n1, int64_t n2_capacity, int64_t max_queries, void* index,
                              float* dists, long long* idx, void* stream);
+/* The resident index at a caller-chosen resolution (cells per axis, 4 .. 256) for query sets the map-tuned rule does not fit:
+ * frame-to-model odometry (PointFusion._localize behind online_adaption.py:362) asks 19 200 queries of a sparse target set,
+ * possibly decimetres away while the pose is still wrong -- a coarse grid bounds the walk over empty cells.  Identical results
+ * at any resolution.  ref_points / warm_idx: both NULL (cold search) or both set (candidates from an earlier search). */
+int64_t e2e_knn1_index_capacity_bytes_res(int64_t max_queries, int64_t n2_capacity, int cells_per_axis);
+int e2e_knn1_index_build_dev_res(const float* p2, const long long* n2_dev, int64_t n2_capacity, int64_t max_queries,
+                                 void* index, int cells_per_axis, void* stream);
+int e2e_knn1_index_query_dev_res(const float* p1, int64_t n1, const float* ref_points, const long long* warm_idx,
+                                 int64_t n2_capacity, int64_t max_queries, void* index, int cells_per_axis,
+                                 float* dists, long long* idx, void* stream);
 /* The same query for queries that are the pixels of an image (row-major, `row_len` pixels per row, n1 a whole number of rows -- the
  * back-projected depth map of the 3-D loss, online_adaption.py:638-645): the lanes of a wave take 8 x 8 pixel tiles, whose points share
  * their grid cells, instead of 64 consecutive pixels of a row.  Results are identical; row_len = 0 (or sizes that are not multiples of 8)

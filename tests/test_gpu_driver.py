@@ -386,46 +386,60 @@ def test_off_by_default_loss_flags_vs_oracle(flags):
 
 def test_map_update_forward_is_reused_as_the_next_keyframes_first_forward():
     """online_adaption.py:329-345 runs the refined network on the pair (p, c) for the map update; :281 of the NEXT keyframe (c, n) runs it on
-    frame c again -- same weights (no optimiser step in between), same input.  The plan moves c's activations from batch slot 1 to slot 0
-    and forwards only n (RefineStepPlan._forward_new_target).  Checked: (a) every activation, the disparity, the scaled depths and the ratio
-    of that shortcut against the plain two-frame forward -- equal to fp32 rounding (a one-image launch may split K differently);
-    (b) a three-keyframe run with and without the shortcut: first keyframe bit-identical, the later keyframes' losses to 1e-5."""
+    frame c again -- same weights (no optimiser step in between), same input.  The plan does not compute it twice:
+      "source"   (no next pair known at map-update time): c's activations move from batch slot 1 to slot 0 and only n is forwarded
+                 (RefineStepPlan._forward_new_target);
+      "prefetch" (next pair known): n is forwarded NEXT TO the map step, on a second stream inside the captured map graph
+                 (update_map(prefetch=True)); the next keyframe's first forward is the median scaling alone (_scale_only).
+    Checked: (a) every activation, the scaled depths and the ratio of both shortcuts against the plain two-frame forward -- equal to fp32
+    rounding (a one-image launch may split K differently); (b) three keyframes in each mode against recomputation: first keyframe
+    bit-identical, later losses to 1e-5, map size to 0.2 %."""
     from e2ehip.synthetic import make_sequence
     from online_adaption import SLAM
     H, W, L = 64, 96, 4
     sd = depthnet.random_state_dict(0)
     sd["decoder.decoder.10.conv.weight"] = sd["decoder.decoder.10.conv.weight"] * 40.0
     seq = make_sequence(L, H, W, seed=17)
-    logs = {}
-    for reuse in (True, False):
+    logs, maps = {}, {}
+    for mode in ("prefetch", "source", "off"):
         slam = SLAM(_cfg(H, W, L), sequence=seq, state_dict=sd)
-        slam.reuse_forward = reuse
+        slam.reuse_forward = mode != "off"
         slam.set_refinement_mode()
         slam.first_iter = True
         sched = slam.keyframe_schedule()
         assert sched == [(0, 1), (1, 2), (2, 3)]
-        slam.refinement(*sched[0], next_pair=sched[1])
+        nxt = (lambda i: sched[i + 1] if (mode != "source" and i + 1 < len(sched)) else None)
+        slam.refinement(*sched[0], next_pair=nxt(0))
         slam.first_iter = False
-        if reuse:                                           # (a) at the hand-over point of keyframe 1 -> 2
-            sp = slam.step_plan
-            assert slam._forward_holds == 1
-            sp._forward_new_target()
+        sp = slam.step_plan
+        if mode != "off":                                   # (a) at the hand-over point of keyframe 1 -> 2
+            assert slam._forward_holds == ((1, 2) if mode == "prefetch" else (None, 1))
+            if mode == "source":
+                slam._load_pair(sp, 1, 2)
+                sp._forward_new_target()
+            else:
+                sp._scale_only()
             torch.cuda.synchronize()
             short = {"acts": [op.out.t.clone() for op in sp.net.ops], "depth": sp.depth.clone(), "ratio": sp.ratio.clone()}
             sp._forward()
             torch.cuda.synchronize()
-            for i, (a, op) in enumerate(zip(short["acts"], sp.net.ops)):
-                assert torch.equal(a[0], op.out.t[0]) or float((a[0] - op.out.t[0]).abs().max()) <= 2e-5 * float(op.out.t[0].abs().max()), i
-                assert float((a[1] - op.out.t[1]).abs().max()) <= 2e-5 * float(op.out.t[1].abs().max()) + 1e-12, i
+            for i, (act, op) in enumerate(zip(short["acts"], sp.net.ops)):
+                for slot in (0, 1):
+                    assert float((act[slot] - op.out.t[slot]).abs().max()) <= 2e-5 * float(op.out.t[slot].abs().max()) + 1e-12, (mode, i, slot)
             torch.testing.assert_close(short["depth"], sp.depth, rtol=2e-5, atol=1e-7)
             torch.testing.assert_close(short["ratio"], sp.ratio, rtol=2e-6, atol=0)
-            slam._forward_holds = None                      # slot 1 now holds frame 2: keyframe 2 takes the plain forward, keyframe 3 the shortcut
+            slam._forward_holds = None                      # the slots now hold the plain forward of (1, 2): keyframe 2 takes the plain path,
+            slam._preloaded = (1, 2)                        # keyframe 3 the shortcut again
         for i in (1, 2):
-            slam.refinement(*sched[i], next_pair=sched[i + 1] if i + 1 < len(sched) else None)
-        logs[reuse] = torch.stack(slam.log)
+            slam.refinement(*sched[i], next_pair=nxt(i))
+        logs[mode], maps[mode] = torch.stack(slam.log), slam.map.M
+        if mode == "prefetch":
+            assert any(isinstance(k, tuple) and k[0] == "map" and k[-1] is True for k in sp._graphs) and "scale_only" in sp._graphs
         slam.close()
-    assert torch.equal(logs[True][:3], logs[False][:3])
-    np.testing.assert_allclose(logs[True][3:].numpy(), logs[False][3:].numpy(), rtol=1e-5, atol=1e-7)
+    for mode in ("prefetch", "source"):
+        assert torch.equal(logs[mode][:3], logs["off"][:3]), mode
+        np.testing.assert_allclose(logs[mode][3:].numpy(), logs["off"][3:].numpy(), rtol=1e-5, atol=2.5 / (H * W))
+        assert abs(maps[mode] - maps["off"]) <= 0.002 * maps["off"], (mode, maps)
 
 
 def test_sparse_depth_supervision_runs():
