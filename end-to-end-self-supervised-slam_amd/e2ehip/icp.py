@@ -108,7 +108,7 @@ class ResidentOdometry:
     check() together with the target-capacity overflow flag wherever the host synchronises anyway."""
 
     def __init__(self, fmap, dsratio=4, numiters=20, mode="gradicp", damp=1e-8, dist_thresh=None, lambda_max=2.0, B=1.0, B2=1.0, nu=200.0,
-                 target_capacity=None, grid_cells=32):
+                 target_capacity=None, grid_cells=128):
         if mode not in ("icp", "gradicp"):
             raise ValueError(f"unknown odometry mode {mode}")
         self.map, self.ds, self.numiters, self.mode = fmap, int(dsratio), int(numiters), mode

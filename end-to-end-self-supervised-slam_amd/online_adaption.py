@@ -73,6 +73,7 @@ class SLAM:
         # first forward of frame c in keyframe (c, n) -- same weights, same input -- and is not computed twice.  E2E_REUSE_FORWARD=0: off
         self.reuse_forward = os.environ.get("E2E_REUSE_FORWARD", "1") == "1"
         self._forward_holds = None
+        self.prefetch_forward = os.environ.get("E2E_PREFETCH_FORWARD", "0") == "1"
         # test hooks (the median ELEMENT of the predictions is where two correct fp32 evaluations of this loop can part: among 614 400
         # depths the median's neighbours lie ~1e-6 away; tests name one run's elements to the other and compare everything else):
         # median_elements[k]: device int32 indices for refinement step k of this object; median_elements_log: filled when it is a list
@@ -314,7 +315,10 @@ class SLAM:
         if next_pair is not None:
             self._load_pair(sp, *next_pair)
             self._preloaded = tuple(next_pair)
-            prefetch = self.reuse_forward and next_pair[0] == cur
+            # (measured, profiles/r04_prefetch_forward_ab.txt: the second stream inside the map graph makes the step SLOWER -- 194.5 against
+            #  201.1 steps/s -- the forward's GEMMs and the map step's memory-bound kernels take more from each other than the overlap gives
+            #  back, as round 3 found for backward-weight next to backward-data; the sequential single-frame forward stays the default)
+            prefetch = self.prefetch_forward and self.reuse_forward and next_pair[0] == cur
         if a.MODEL.odom == "gt":
             sp.update_map(self.map, self.first_iter, prefetch=prefetch)
         else:
@@ -330,7 +334,8 @@ class SLAM:
     def _odometry(self):
         if getattr(self, "_odo", None) is None:
             from e2ehip.icp import ResidentOdometry
-            self._odo = ResidentOdometry(self.map, dsratio=4, numiters=self.args.MODEL.numiters, mode=self.args.MODEL.odom)
+            self._odo = ResidentOdometry(self.map, dsratio=4, numiters=self.args.MODEL.numiters, mode=self.args.MODEL.odom,
+                                         grid_cells=int(os.environ.get("E2E_ICP_CELLS", "128")))
         return self._odo
 
     def _log_step(self, rec, refine_step, nsteps):

@@ -404,6 +404,7 @@ def test_map_update_forward_is_reused_as_the_next_keyframes_first_forward():
     for mode in ("prefetch", "source", "off"):
         slam = SLAM(_cfg(H, W, L), sequence=seq, state_dict=sd)
         slam.reuse_forward = mode != "off"
+        slam.prefetch_forward = mode == "prefetch"
         slam.set_refinement_mode()
         slam.first_iter = True
         sched = slam.keyframe_schedule()

@@ -10,10 +10,14 @@
 #   pass_profile.txt            tools/pass_profile.py: wall time per keyframe over a whole pass + the map-size dependent entry points
 #   conv_stamps.txt             scratch/conv_stamps.py on the -DE2E_CONV_STAMPS build (if scratch/_stamped/ holds one)
 #   pytest_gpu.log              python3 -m pytest tests -m gpu -q
+# usage: tools/evidence.sh <tag> [bench|suite]   -- two parts, each within one gpurun call (20 minutes): "bench" = PMC traffic, the bench lines and
+# the rocprofv3 kernel statistics; "suite" = GEMM table, pass profile, GPU test log.  Default: both.
 export TMPDIR=/tmp
 TAG=$1
+PART=${2:-all}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/evidence_$TAG; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
+if [ "$PART" != "suite" ]; then
 # PMC traffic FIRST: bench.py reports roofline.traffic from profiles/r04_bench_pmc_traffic.json only if that record carries the stamp of the build it runs
 bash tools/bench_pmc.sh $TAG > $OUT/pmc.log 2>&1
 cp gpurun_out/benchpmc_$TAG/traffic.txt $OUT/pmc_traffic.txt; cp gpurun_out/benchpmc_$TAG/traffic.json $OUT/pmc_traffic.json
@@ -24,7 +28,7 @@ python3 bench.py --gpus 1 --steps 177 --warmup 6 --no-cpu-baseline > $OUT/bench_
 cp $OUT/bench_fullpass.json profiles/r04_bench_seq_fullpass.json
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default $?" >> $OUT/progress.txt
 E2E_WGRAD_OVERLAP=1 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/bench_overlap.json 2> $OUT/bench_overlap.err; echo "overlap $?" >> $OUT/progress.txt
-timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --odom gradicp > $OUT/bench_gradicp.json 2> $OUT/bench_gradicp.err; echo "gradicp $?" >> $OUT/progress.txt
+timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-roofline --odom gradicp > $OUT/bench_gradicp.json 2> $OUT/bench_gradicp.err; echo "gradicp $?" >> $OUT/progress.txt
 rocprofv3 --kernel-trace --stats -d /tmp/ev_$TAG -o full --output-format csv -- python3 bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 echo "rocprof $?" >> $OUT/progress.txt
 f=$(find /tmp/ev_$TAG -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/kernel_stats.csv
@@ -38,8 +42,11 @@ print(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 60
 for r in rows[:70]:
     print(f"{r['Name'][:90]:90s} calls {r['Calls']:>6s} avg_us {float(r['AverageNs'])/1e3:9.1f} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} {100*float(r['TotalDurationNs'])/tot:5.1f}%")
 PY
+fi
+if [ "$PART" != "bench" ]; then
 timeout -k 10 500 python3 tools/gemm_tune.py both > $OUT/gemm_tune.txt 2>&1; echo "tune $?" >> $OUT/progress.txt
 timeout -k 10 300 python3 tools/pass_profile.py > $OUT/pass_profile.txt 2> $OUT/pass_profile.err; echo "pass profile $?" >> $OUT/progress.txt
 if [ -f scratch/_stamped/libe2eslam_hip_stamped.so ]; then python3 scratch/conv_stamps.py 2>&1 | grep -v amdgpu.ids > $OUT/conv_stamps.txt; echo "stamps $?" >> $OUT/progress.txt; fi
-timeout -k 10 900 python3 -m pytest tests -m gpu -q --durations=5 > $OUT/pytest_gpu.log 2>&1; echo "pytest $?" >> $OUT/progress.txt
+timeout -k 10 600 python3 -m pytest tests -m gpu -q --durations=5 > $OUT/pytest_gpu.log 2>&1; echo "pytest $?" >> $OUT/progress.txt
+fi
 cat $OUT/progress.txt; head -c 300 $OUT/bench_default.json; echo; head -c 300 $OUT/bench_fullpass.json; echo; head -c 300 $OUT/bench_gradicp.json
