@@ -1918,17 +1918,20 @@ __global__ __launch_bounds__(256) void k_wgrad7x7_stem(StemWgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Backward-weight of the 3x3 stride-1 pad-1 layers with 64-channel tiles, TAP-REUSE form (round 4).
+// Backward-weight of the 3x3 stride-1 pad-1 layers with 32-channel tiles, TAP-REUSE form (round 4).
 //   dW[co][ci][kh][kw] = sum over pixels  dZ[p][co] * Xpad[p + (kh - 1, kw - 1)][ci]
 // The implicit-GEMM kernels above treat (tap, ci) as the GEMM's N dimension and gather every (pixel, tap, channel) operand per chunk:
 // 16 MFMAs per 2 x 16 KB of staged operands, ~12 vector instructions per MFMA of address arithmetic.  Here a
-// workgroup stages ONE 8 x 8 pixel patch of dZ (64 co) and the patch + 1-pixel halo of X (10 x 10, 64 ci) and runs ALL NINE taps from
-// it -- the tap is a constant LDS offset: 288 MFMAs per wave and chunk from 41 KB of operands (9 x the reuse), no per-tap addressing.
-// Each wave owns one 32 x 32 (co, ci) block and nine accumulators (one per tap); a k-step is one dZ fragment read + nine X reads.
+// workgroup stages ONE 8 x 8 pixel patch of dZ (32 co) and the patch + 1-pixel halo of X (10 x 10, 32 ci) and runs ALL NINE taps from
+// it -- a tap is a constant LDS offset: 288 MFMAs per chunk from 21 KB of operands, no per-tap addressing.  Three waves: wave w owns the
+// kernel row kh = w, i.e. three accumulators (kw = 0, 1, 2) of the workgroup's 32 x 32 (co, ci) block over ALL 64 pixels -- no
+// cross-wave sum, 48 accumulator registers per lane.  A k-step (2 pixels) is one dZ fragment read + three X reads + three MFMAs.
 // Pixel slices (grid.z) write slabs [S][Mpad][Npad] in the layout of the kernels above (column = tap * Cin + ci, bias column 9 Cin):
-// k_wgrad_reduce is shared.  Rows of LDS are padded to 96 floats: the two k-halves of a wave (lanes 0-31 / 32-63) then read disjoint banks.
-// X gather: zero or reflection padding, optional x2 nearest upsample of src0 and a channel-concatenated src1 (a 64-channel tile lies in
-// one source: C1 % 64 == 0).
+// k_wgrad_reduce is shared.  (A first form with 64 x 64 tiles and nine accumulators per wave ran 30 % SLOWER than the GEMM it replaced:
+// a workgroup's slab is 9 x its tile, 512 workgroups wrote 75 MB of slabs per layer against 13 MB -- profiles/r04_wgrad_taps.txt.)
+// ds_read_b32 banks are per 32-lane half (lanes l and l + 32 never conflict): rows of 32 floats are conflict-free.
+// X gather: zero or reflection padding, optional x2 nearest upsample of src0 and a channel-concatenated src1 (a 32-channel tile lies in
+// one source: C1 % 32 == 0).
 // ---------------------------------------------------------------------------------------------------------------------
 struct TapWgradArgs {
     const float* dz;       // (B, H, W, Cout)
@@ -1940,46 +1943,45 @@ struct TapWgradArgs {
     int nchunks, cps;      // chunks (patch of one image) in total / per slice
 };
 
-#define TAP_LD 96
+#define TAP_NT 192
 template <bool BIAS>
-__global__ __launch_bounds__(256, BIAS ? 1 : 2) void k_wgrad3x3_taps(TapWgradArgs a) {
-    __shared__ float dzs[64 * TAP_LD];
-    __shared__ float xs[100 * TAP_LD];
+__global__ __launch_bounds__(TAP_NT) void k_wgrad3x3_taps(TapWgradArgs a) {
+    __shared__ float dzs[64 * 32];                                  // [pixel][co]
+    __shared__ float xs[100 * 32];                                  // [halo pixel][ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh_ = lane >> 5, l32 = lane & 31;
-    const int cb = wave >> 1, nb = wave & 1;
-    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
-    const bool first = ci0 < a.C1;                                  // this tile's 64 input channels: of src0 (behind the upsample) or of src1
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const bool first = ci0 < a.C1;                                  // this tile's 32 input channels: of src0 (behind the upsample) or of src1
     const int sh = first ? (a.up >> 1) : 0, Cs = first ? a.C1 : a.Cin - a.C1, cs0 = first ? ci0 : ci0 - a.C1;
     const int Hs = a.H >> sh, Ws = a.W >> sh;
     const float* sbase = first ? a.src0 : a.src1;
     const int c_begin = blockIdx.z * a.cps, c_end = min(c_begin + a.cps, a.nchunks);
-    const bool want_bias = BIAS && blockIdx.x == 0 && nb == 0;
-    f16v acc[9], accb;
+    const bool want_bias = BIAS && blockIdx.x == 0 && wave == 0;
+    f16v acc[3], accb;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
     const float one = (l32 == 0) ? 1.f : 0.f;
-    f4v rz[4], rx[7];
+    f4v rz[3], rx[5];
     auto load_chunk = [&](int g) {
         const int b = g / (a.pty * a.ptx), rem = g - b * (a.pty * a.ptx), py = rem / a.ptx, px = rem - py * a.ptx;
         const int y0 = py * 8, x0 = px * 8;
         const float* zb = a.dz + (int64_t)b * a.H * a.W * a.Cout + co0;
         const float* sb = sbase + (int64_t)b * Hs * Ws * Cs + cs0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 256 * i, pix = f >> 4, q = f & 15, y = y0 + (pix >> 3), x = x0 + (pix & 7);
-            const bool ok = y < a.H && x < a.W;
+        for (int i = 0; i < 3; ++i) {
+            const int f = tid + TAP_NT * i, pix = f >> 3, q = f & 7, y = y0 + (pix >> 3), x = x0 + (pix & 7);
+            const bool ok = f < 512 && y < a.H && x < a.W;
             rz[i] = ok ? *(const f4v*)(zb + ((int64_t)y * a.W + x) * a.Cout + q * 4) : (f4v){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int f = tid + 256 * i;
+        for (int i = 0; i < 5; ++i) {
+            const int f = tid + TAP_NT * i;
             f4v v = {0.f, 0.f, 0.f, 0.f};
-            if (f < 1600) {
-                const int pix = f >> 4, q = f & 15;
+            if (f < 800) {
+                const int pix = f >> 3, q = f & 7;
                 int y = y0 - 1 + pix / 10, x = x0 - 1 + pix % 10;
                 bool ok = true;
                 if (a.reflect) {                                    // (beyond the image's far edge by more than the pad: the patch overhangs, dZ is 0 there)
@@ -1995,51 +1997,44 @@ __global__ __launch_bounds__(256, BIAS ? 1 : 2) void k_wgrad3x3_taps(TapWgradArg
     };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 256 * i;
-            *(f4v*)&dzs[(f >> 4) * TAP_LD + (f & 15) * 4] = rz[i];
+        for (int i = 0; i < 3; ++i) {
+            const int f = tid + TAP_NT * i;
+            if (f < 512) *(f4v*)&dzs[f * 4] = rz[i];                 // [pixel f >> 3][quad f & 7]: contiguous
         }
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int f = tid + 256 * i;
-            if (f < 1600) *(f4v*)&xs[(f >> 4) * TAP_LD + (f & 15) * 4] = rx[i];
+        for (int i = 0; i < 5; ++i) {
+            const int f = tid + TAP_NT * i;
+            if (f < 800) *(f4v*)&xs[f * 4] = rx[i];
         }
     };
     if (c_begin < c_end) load_chunk(c_begin);
-    const float* ap = dzs + kh_ * TAP_LD + cb * 32 + l32;               // A[m = co][k = pixel]: dZ[pixel 2 ks + (lane >> 5)][co]
-    const float* bp = xs + kh_ * TAP_LD + nb * 32 + l32;                // B[k = pixel][n = ci]: X[halo pixel of (pixel + tap)][ci]
+    const float* ap = dzs + kh_ * 32 + l32;                             // A[m = co][k = pixel]: dZ[pixel 2 ks + (lane >> 5)][co]
+    const float* bp = xs + (kh_ + wave * 10) * 32 + l32;                // B[k = pixel][n = ci]: X[halo pixel of (pixel + (kh = wave, kw))][ci]
     for (int c = c_begin; c < c_end; ++c) {
         __syncthreads();                                                // the previous chunk's fragments are consumed
         store_chunk();
         __syncthreads();
-        if (c + 1 < c_end) load_chunk(c + 1);                           // in flight under the 288 MFMAs below
+        if (c + 1 < c_end) load_chunk(c + 1);                           // in flight under the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < 32; ++ks) {
-            const float av = ap[2 * ks * TAP_LD];
+            const float av = ap[2 * ks * 32];
             const int q0 = (ks >> 2) * 10 + 2 * (ks & 3);               // halo index of the k-step's first pixel at tap (0, 0)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float bv = bp[(q0 + (t / 3) * 10 + (t % 3)) * TAP_LD];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-            }
+            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[(q0 + t) * 32], acc[t], 0, 0, 0);
             if (BIAS && want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(av, one, accb, 0, 0, 0);
         }
     }
     float* slab = a.slabs + (int64_t)blockIdx.z * a.Mpad * a.Npad;
-    const int n_in = ci0 + nb * 32 + l32;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh_;
-            slab[(int64_t)m * a.Npad + t * a.Cin + n_in] = acc[t][r];
+            const int m = co0 + (r & 3) + 8 * (r >> 2) + 4 * kh_;
+            slab[(int64_t)m * a.Npad + (wave * 3 + t) * a.Cin + ci0 + l32] = acc[t][r];
         }
     if (BIAS && want_bias && l32 == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh_;
-            slab[(int64_t)m * a.Npad + 9 * a.Cin] = accb[r];
-        }
+        for (int r = 0; r < 16; ++r) slab[(int64_t)(co0 + (r & 3) + 8 * (r >> 2) + 4 * kh_) * a.Npad + 9 * a.Cin] = accb[r];
     }
 }
 
@@ -2888,15 +2883,15 @@ static ThinWgradPlan thin_wgrad_plan(int B, int Ho, int Wo, int Cin, int has_bia
     return p;
 }
 
-// decomposition of k_wgrad3x3_taps: (Cin / 64) x (Cout / 64) tiles x S pixel slices of whole 8 x 8 patches, ~TAP_TARGET workgroups
-#define TAP_TARGET 512
+// decomposition of k_wgrad3x3_taps: (Cin / 32) x (Cout / 32) tiles x S pixel slices of whole 8 x 8 patches, ~TAP_TARGET workgroups of 3 waves
+#define TAP_TARGET 640
 struct TapWgradPlan { int ptx, pty, nchunks, cps, S, Npad; };
-static bool tap_wgrad_shape_ok(int Cin, int Cout, int KH, int KW) { return KH == 3 && KW == 3 && Cin % 64 == 0 && Cout % 64 == 0; }
+static bool tap_wgrad_shape_ok(int Cin, int Cout, int KH, int KW) { return KH == 3 && KW == 3 && Cin % 32 == 0 && Cout % 32 == 0; }
 static TapWgradPlan tap_wgrad_plan(int B, int H, int W, int Cin, int Cout, int has_bias) {
     TapWgradPlan p;
     p.ptx = (W + 7) / 8; p.pty = (H + 7) / 8;
     p.nchunks = B * p.ptx * p.pty;
-    const int tiles = (Cin / 64) * (Cout / 64);
+    const int tiles = (Cin / 32) * (Cout / 32);
     int S = (TAP_TARGET + tiles - 1) / tiles;
     if (S > p.nchunks) S = p.nchunks;
     if (S < 1) S = 1;
@@ -2970,15 +2965,15 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
         E2E_LAUNCH_CHECK("e2e_conv2d_bwd_weight");
         return E2E_OK;
     }
-    // the 64-channel-tile 3x3 layers (encoder stages, decoder upconv(k, 0) and the concat layers whose two sources are multiples of 64 wide):
+    // the 32-channel-tile 3x3 layers (encoder stages, decoder upconv(k, 0) and the concat layers whose two sources are multiples of 32 wide):
     // tap-reuse patch kernel + the common slab reduction
     if (!tuned && vec == 4 && tap_wgrad_shape_ok(Cin, Cout, KH, KW) && stride == 1 && pad == 1 && Ho == Hs && Wo == Ws && (up == 1 || up == 2) &&
-        Hs % up == 0 && Ws % up == 0 && (C1 == Cin || (src1 && C1 % 64 == 0)) && getenv("E2E_WGRAD_TAPS_OFF") == nullptr) {
+        Hs % up == 0 && Ws % up == 0 && (C1 == Cin || (src1 && C1 % 32 == 0)) && getenv("E2E_WGRAD_TAPS_OFF") == nullptr) {
         const TapWgradPlan t = tap_wgrad_plan(B, Ho, Wo, Cin, Cout, a.has_bias);
         TapWgradArgs ta{dz, src0, src1, workspace, B, Ho, Wo, Cin, C1, up, Cout, pad_mode == 1 ? 1 : 0, a.has_bias, Cout, t.Npad, t.ptx, t.pty, t.nchunks, t.cps};
-        const dim3 tg((unsigned)(Cin / 64), (unsigned)(Cout / 64), (unsigned)t.S);
-        if (a.has_bias) hipLaunchKernelGGL(k_wgrad3x3_taps<true>, tg, dim3(256), 0, st, ta);
-        else hipLaunchKernelGGL(k_wgrad3x3_taps<false>, tg, dim3(256), 0, st, ta);
+        const dim3 tg((unsigned)(Cin / 32), (unsigned)(Cout / 32), (unsigned)t.S);
+        if (a.has_bias) hipLaunchKernelGGL(k_wgrad3x3_taps<true>, tg, dim3(TAP_NT), 0, st, ta);
+        else hipLaunchKernelGGL(k_wgrad3x3_taps<false>, tg, dim3(TAP_NT), 0, st, ta);
         const int64_t tq = (int64_t)Cout * ((a.Ngemm + 3) / 4);
         if (t.S >= 8)
             hipLaunchKernelGGL((k_wgrad_reduce<8>), dim3(egrid(tq * 4)), dim3(512), 0, st, workspace, t.S, Cout, t.Npad, Cout, Cin, KH, KW, a.has_bias, dw, dbias,

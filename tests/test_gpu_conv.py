@@ -69,11 +69,13 @@ CASES = [
     (2, 32, 64, 2, 240, 320, 32, 3, 1, 1, "reflect", "elu", False, True, False),  # upconv(1,1): 96 -> 32 with upsample + skip, 153 600 rows
     (2, 16, 0, 2, 480, 640, 16, 3, 1, 1, "reflect", "elu", False, True, False),   # upconv(0,1): 16 -> 16 at full resolution, 614 400 rows
     (2, 256, 0, 1, 30, 40, 256, 3, 1, 1, "zeros", "relu", True, False, True),     # layer3: split-K territory
-    # 64-channel-tile 3x3 layers: backward-weight runs the tap-reuse patch kernel (k_wgrad3x3_taps) -- odd sizes (patches that overhang the
+    # 32-channel-tile 3x3 layers: backward-weight runs the tap-reuse patch kernel (k_wgrad3x3_taps) -- odd sizes (patches that overhang the
     # image), reflection padding with a bias column, upsample + concat with both sources multiples of 64 wide, several ci / co tiles
     (2, 128, 0, 1, 15, 20, 64, 3, 1, 1, "reflect", "elu", False, True, False),    # upconv(k,0)-like, 15 x 20 (layer4 resolution)
     (1, 64, 64, 2, 16, 24, 64, 3, 1, 1, "reflect", "elu", False, True, False),    # upconv(2,1): 64 upsampled + 64 skip channels
-    (2, 192, 0, 1, 9, 11, 128, 3, 1, 1, "zeros", None, False, False, False),      # 3 x 2 tiles, patches wider than the image remainder
+    (2, 192, 0, 1, 9, 11, 128, 3, 1, 1, "zeros", None, False, False, False),      # 6 x 4 tiles, patches wider than the image remainder
+    (2, 64, 0, 1, 24, 40, 32, 3, 1, 1, "reflect", "elu", False, True, False),     # upconv(1,0): 64 -> 32, one co tile with the bias column
+    (1, 32, 32, 2, 16, 16, 32, 3, 1, 1, "reflect", "elu", False, True, False),    # concat with 32-channel sources (one ci tile per source)
 ]
 
 

@@ -82,7 +82,15 @@ def main():
                     L.call("e2e_conv2d_bwd_weight_scaled_tuned", L.ptr(dz), None, L.ptr(x), L.ptr(skip), Cx, up, L.ptr(dw), L.ptr(db), L.ptr(wsw), B, H, W, Cin, Cout,
                            Ho, Wo, k, k, s, p, pm, 0, 0.0, 1.0, tgt, st)
                 res.append((timeit(wg), tgt))
-            print(f"{name:10s} wgrad {gf:5.2f} GF | " + " ".join(f"{tgt}:{t:.1f}" for t, tgt in res) + f"  (best {min(res)[1]}: {gf / min(res)[0] * 1e3:.1f} TF/s)", flush=True)
+            # what the product launches (the library's own choice: the tap-reuse patch kernel where the layer is eligible, else its GEMM rule)
+            wsd = torch.empty(lib.e2e_conv2d_wgrad_workspace_floats(B, Ho, Wo, Cin, Cout, k, k, 1), device=DEV)
+
+            def wd():
+                L.call("e2e_conv2d_bwd_weight_scaled", L.ptr(dz), None, L.ptr(x), L.ptr(skip), Cx, up, L.ptr(dw), L.ptr(db), L.ptr(wsd), B, H, W, Cin, Cout,
+                       Ho, Wo, k, k, s, p, pm, 0, 0.0, 1.0, st)
+            t_prod = timeit(wd)
+            print(f"{name:10s} wgrad {gf:5.2f} GF | " + " ".join(f"{tgt}:{t:.1f}" for t, tgt in res) + f"  (best {min(res)[1]}: {gf / min(res)[0] * 1e3:.1f} TF/s)"
+                  f"  || product default {t_prod:.1f} us ({gf / t_prod * 1e3:.1f} TF/s)", flush=True)
         for tag, fn, ncols, K in (("fwd", fwd, Cout, k * k * Cin), ("bwd", bwd, Cin, k * k * Cout)):
             if which not in ("both", tag):
                 continue
