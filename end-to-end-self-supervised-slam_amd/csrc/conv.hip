@@ -2015,14 +2015,42 @@ __global__ __launch_bounds__(TAP_NT) void k_wgrad3x3_taps(TapWgradArgs a) {
         store_chunk();
         __syncthreads();
         if (c + 1 < c_end) load_chunk(c + 1);                           // in flight under the MFMAs below
+        // fragments of HALF a chunk (16 k-steps: 16 dZ + 48 X values per lane) are read ahead of their 48 MFMAs, the second half's
+        // reads are issued before the first half's MFMAs: hipcc otherwise emits read -> s_waitcnt lgkmcnt(0) -> 1..3 MFMAs per k-step
+        // and the LDS round trip is paid 32 times per chunk (the first build of this kernel ran at 45-57 TF/s that way)
+        float av[2][16], bv[2][16][3];
+        auto read_half = [&](int h) {
 #pragma unroll
-        for (int ks = 0; ks < 32; ++ks) {
-            const float av = ap[2 * ks * 32];
-            const int q0 = (ks >> 2) * 10 + 2 * (ks & 3);               // halo index of the k-step's first pixel at tap (0, 0)
+            for (int j = 0; j < 16; ++j) {
+                const int ks = 16 * h + j, q0 = (ks >> 2) * 10 + 2 * (ks & 3);      // halo index of the k-step's first pixel at tap (0, 0)
+                av[h][j] = ap[2 * ks * 32];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[(q0 + t) * 32], acc[t], 0, 0, 0);
-            if (BIAS && want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(av, one, accb, 0, 0, 0);
+                for (int t = 0; t < 3; ++t) bv[h][j][t] = bp[(q0 + t) * 32];
+            }
+        };
+        auto pin_half = [&](int h) {            // the half's fragments exist in registers HERE (the scheduler may not sink their reads past this point)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                asm volatile("" : "+v"(av[h][j]));
+#pragma unroll
+                for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(bv[h][j][t]));
+            }
+        };
+        read_half(0);
+        read_half(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            pin_half(h);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][j], bv[h][j][t], acc[t], 0, 0, 0);
+                if (BIAS && want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][j], one, accb, 0, 0, 0);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
     float* slab = a.slabs + (int64_t)blockIdx.z * a.Mpad * a.Npad;
 #pragma unroll
