@@ -2015,42 +2015,44 @@ __global__ __launch_bounds__(TAP_NT) void k_wgrad3x3_taps(TapWgradArgs a) {
         store_chunk();
         __syncthreads();
         if (c + 1 < c_end) load_chunk(c + 1);                           // in flight under the MFMAs below
-        // fragments of HALF a chunk (16 k-steps: 16 dZ + 48 X values per lane) are read ahead of their 48 MFMAs, the second half's
-        // reads are issued before the first half's MFMAs: hipcc otherwise emits read -> s_waitcnt lgkmcnt(0) -> 1..3 MFMAs per k-step
-        // and the LDS round trip is paid 32 times per chunk (the first build of this kernel ran at 45-57 TF/s that way)
-        float av[2][16], bv[2][16][3];
-        auto read_half = [&](int h) {
+        // fragments are read QB k-steps (QB dZ + 3 QB X values per lane) ahead of their 3 QB MFMAs, two register sets: the reads of batch
+        // q + 1 are issued before the MFMAs of batch q.  hipcc left alone emits read -> s_waitcnt lgkmcnt(0) -> 1..3 MFMAs per k-step (the
+        // LDS round trip paid 32 times per chunk); reading half a chunk ahead costs 183 registers, two waves per SIMD and a second round of
+        // workgroups; QB = 4 keeps three waves per SIMD -- profiles/r04_wgrad_taps.txt
+        constexpr int QB = 4, NQ = 32 / QB;
+        float av[2][QB], bv[2][QB][3];
+        auto read_q = [&](int set, int qt) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int ks = 16 * h + j, q0 = (ks >> 2) * 10 + 2 * (ks & 3);      // halo index of the k-step's first pixel at tap (0, 0)
-                av[h][j] = ap[2 * ks * 32];
+            for (int j = 0; j < QB; ++j) {
+                const int ks = QB * qt + j, q0 = (ks >> 2) * 10 + 2 * (ks & 3);     // halo index of the k-step's first pixel at tap (0, 0)
+                av[set][j] = ap[2 * ks * 32];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) bv[h][j][t] = bp[(q0 + t) * 32];
+                for (int t = 0; t < 3; ++t) bv[set][j][t] = bp[(q0 + t) * 32];
             }
         };
-        auto pin_half = [&](int h) {            // the half's fragments exist in registers HERE (the scheduler may not sink their reads past this point)
+        auto pin_q = [&](int set) {              // the set's fragments exist in registers HERE (the scheduler may not sink their reads past this point)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                asm volatile("" : "+v"(av[h][j]));
+            for (int j = 0; j < QB; ++j) {
+                asm volatile("" : "+v"(av[set][j]));
 #pragma unroll
-                for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(bv[h][j][t]));
+                for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(bv[set][j][t]));
             }
         };
-        read_half(0);
-        read_half(1);
-        __builtin_amdgcn_sched_barrier(0);
+        read_q(0, 0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            pin_half(h);
+        for (int qt = 0; qt < NQ; ++qt) {
+            if (qt + 1 < NQ) read_q((qt + 1) & 1, qt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            pin_q(qt & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < QB; ++j) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][j], bv[h][j][t], acc[t], 0, 0, 0);
-                if (BIAS && want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][j], one, accb, 0, 0, 0);
+                for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[qt & 1][j], bv[qt & 1][j][t], acc[t], 0, 0, 0);
+                if (BIAS && want_bias) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(av[qt & 1][j], one, accb, 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
     float* slab = a.slabs + (int64_t)blockIdx.z * a.Mpad * a.Npad;
 #pragma unroll
