@@ -2922,7 +2922,8 @@ static TapWgradPlan tap_wgrad_plan(int B, int H, int W, int Cin, int Cout, int h
     p.ptx = (W + 7) / 8; p.pty = (H + 7) / 8;
     p.nchunks = B * p.ptx * p.pty;
     const int tiles = (Cin / 32) * (Cout / 32);
-    int S = (TAP_TARGET + tiles - 1) / tiles;
+    static const int target = getenv("E2E_TAP_TARGET") ? atoi(getenv("E2E_TAP_TARGET")) : TAP_TARGET;      // (diagnostic sweep; read once)
+    int S = (target + tiles - 1) / tiles;
     if (S > p.nchunks) S = p.nchunks;
     if (S < 1) S = 1;
     p.cps = (p.nchunks + S - 1) / S;

@@ -46,7 +46,11 @@ def main():
     lib = L.load()
     B = 2
     st = L.stream()
+    only = [x for x in os.environ.get("GEMM_TUNE_LAYERS", "").split(",") if x]
+    product_only = os.environ.get("GEMM_TUNE_PRODUCT_ONLY") == "1"
     for name, Cx, Cs, up, H, W, Cout, k, s, p, pm in LAYERS:
+        if only and name not in only:
+            continue
         Cin = Cx + Cs
         x = torch.randn(B, H // up, W // up, Cx, device=DEV)
         skip = torch.randn(B, H, W, Cs, device=DEV) if Cs else None
@@ -75,7 +79,7 @@ def main():
             dw = torch.empty(Cout, Cin, k, k, device=DEV)
             db = torch.empty(Cout, device=DEV)
             res = []
-            for tgt in (256, 384, 512, 768, 1024, 1536, 2048):
+            for tgt in (() if product_only else (256, 384, 512, 768, 1024, 1536, 2048)):
                 wsw = torch.empty(lib.e2e_conv2d_wgrad_tuned_workspace_floats(B, Ho, Wo, Cin, Cout, k, k, 1, tgt), device=DEV)
 
                 def wg():
@@ -89,7 +93,8 @@ def main():
                 L.call("e2e_conv2d_bwd_weight_scaled", L.ptr(dz), None, L.ptr(x), L.ptr(skip), Cx, up, L.ptr(dw), L.ptr(db), L.ptr(wsd), B, H, W, Cin, Cout,
                        Ho, Wo, k, k, s, p, pm, 0, 0.0, 1.0, st)
             t_prod = timeit(wd)
-            print(f"{name:10s} wgrad {gf:5.2f} GF | " + " ".join(f"{tgt}:{t:.1f}" for t, tgt in res) + f"  (best {min(res)[1]}: {gf / min(res)[0] * 1e3:.1f} TF/s)"
+            best = f"  (best {min(res)[1]}: {gf / min(res)[0] * 1e3:.1f} TF/s)" if res else ""
+            print(f"{name:10s} wgrad {gf:5.2f} GF | " + " ".join(f"{tgt}:{t:.1f}" for t, tgt in res) + best +
                   f"  || product default {t_prod:.1f} us ({gf / t_prod * 1e3:.1f} TF/s)", flush=True)
         for tag, fn, ncols, K in (("fwd", fwd, Cout, k * k * Cin), ("bwd", bwd, Cin, k * k * Cout)):
             if which not in ("both", tag):
