@@ -115,6 +115,15 @@ def test_conv_forward_backward(case):
         assert e < 5e-5, f"grad of tensor {tuple(t.shape)}: {e:.2e}"
 
 
+@pytest.mark.parametrize("case", [c for c in CASES if c[7] == 3 and c[8] == 1 and (c[1] + c[2]) % 32 == 0 and c[6] % 32 == 0 and c[1] % 32 == 0],
+                         ids=lambda c: f"{c[1]}+{c[2]}to{c[6]}_{c[4]}x{c[5]}")
+def test_tap_reuse_backward_weight_kernel(case, monkeypatch):
+    """k_wgrad3x3_taps (opt-in, E2E_WGRAD_TAPS=1: profiles/r04_wgrad_taps.txt) on every eligible case of the table above -- same comparison
+    against float64, so the experimental kernel stays correct while it is not the product's path."""
+    monkeypatch.setenv("E2E_WGRAD_TAPS", "1")
+    test_conv_forward_backward(case)
+
+
 @pytest.mark.parametrize("H,W,act", [(20, 28, "disp"), (5, 7, None), (64, 96, "disp")])
 def test_disparity_head(H, W, act):
     """Conv3x3(reflect) 16 -> 1 (+ 10*sigmoid+0.01): dedicated kernels, forward and all three gradients."""
