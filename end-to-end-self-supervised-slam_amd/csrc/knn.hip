@@ -545,6 +545,31 @@ __global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, 
     }
 }
 
+// Small query sets (frame-to-model odometry: 19 200 queries): EVERY query goes to the wave-per-query pass.  One query per lane means 300
+// waves on 1024 SIMDs, each lane walking its <= 49 cell rows through two dependent loads per row -- 70 us of pure latency; a wave per query
+// spreads the rows of a shell over its lanes and finishes in a few dependent steps.  This kernel only seeds the search: the warm candidate's
+// distance (or "nothing") and the list of all queries.
+__global__ __launch_bounds__(256) void k_knn1_all_unresolved(const float* __restrict__ p1, int64_t n1, GridInfo* __restrict__ gi, unsigned int* __restrict__ unresolved,
+                                                             const float* __restrict__ ref, const long long* __restrict__ warm, float* __restrict__ dists,
+                                                             long long* __restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) gi->n_unresolved = (unsigned int)n1;
+    if (i >= n1) return;
+    long long w = -1;
+    float d = 3.402823466e38f;
+    if (warm) {
+        const long long c = warm[i];
+        if (c >= 0 && c < (long long)gi->n_points) {
+            const float dx = p1[i * 3] - ref[c * 3], dy = p1[i * 3 + 1] - ref[c * 3 + 1], dz = p1[i * 3 + 2] - ref[c * 3 + 2];
+            d = (dx * dx + dy * dy) + dz * dz;                  // the same expression as for every scanned point
+            w = c;
+        }
+    }
+    dists[i] = d;
+    idx[i] = w;
+    unresolved[i] = (unsigned int)i;
+}
+
 extern "C" {
 
 static int knn1_brute(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists, long long* idx, void* workspace, hipStream_t st);
@@ -615,7 +640,12 @@ static void grid_query(const float* p1, int64_t n1, const GridWs& g, float* dist
     if (!ref) warm = nullptr;
     hipLaunchKernelGGL(k_grid_query, dim3((unsigned)((n1 + KT - 1) / KT)), dim3(KT), 0, st, p1, n1, row_len, g.gi, g.starts, g.sorted, dists, idx, g.unresolved, ref,
                        warm);
-    hipLaunchKernelGGL(k_knn1_rest, dim3(1024), dim3(KT), 0, st, p1, g.gi, g.starts, g.sorted, g.unresolved, dists, idx);
+    // one WAVE per unresolved query: 1024 workgroups (4096 waves) suit the refinement queries, of which a few per cent stay unresolved; a small
+    // query set that is mostly unresolved (frame-to-model odometry while the pose is still wrong: 19 200 queries, decimetres off the targets)
+    // gets a wave per query instead of 2-5 queries per wave in sequence -- idle workgroups leave at once
+    const int64_t rest_blocks = n1 <= 65536 ? (n1 + 3) / 4 : 1024;
+    hipLaunchKernelGGL(k_knn1_rest, dim3((unsigned)(rest_blocks < 1024 ? 1024 : (rest_blocks > 8192 ? 8192 : rest_blocks))), dim3(KT), 0, st, p1, g.gi, g.starts,
+                       g.sorted, g.unresolved, dists, idx);
 }
 
 static int knn1_grid(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists, long long* idx, void* workspace, hipStream_t st) {
@@ -708,8 +738,14 @@ int e2e_knn1_index_query_dev_res(const float* p1, int64_t n1, const float* ref_p
     E2E_REQUIRE(p1 && index && dists && idx && n1 > 0 && n1 <= max_queries && n2_capacity > 0 && cells_per_axis >= 4 && cells_per_axis <= GRID_MAX_BIG &&
                 ((ref_points == nullptr) == (warm_idx == nullptr)), E2E_ERR_ARG, "e2e_knn1_index_query_dev_res: bad argument");
     const GridWs g = grid_ws(index, max_queries, n2_capacity, true, cells_per_axis);
-    hipLaunchKernelGGL(k_grid_reset_unresolved, dim3(1), dim3(1), 0, (hipStream_t)stream, g.gi);
-    grid_query(p1, n1, g, dists, idx, (hipStream_t)stream, 0, ref_points, warm_idx);
+    hipStream_t st = (hipStream_t)stream;
+    if (n1 <= 32768) {                                          // a wave per query from the start (see k_knn1_all_unresolved)
+        hipLaunchKernelGGL(k_knn1_all_unresolved, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, p1, n1, g.gi, g.unresolved, ref_points, warm_idx, dists, idx);
+        hipLaunchKernelGGL(k_knn1_rest, dim3((unsigned)((n1 + 3) / 4)), dim3(KT), 0, st, p1, g.gi, g.starts, g.sorted, g.unresolved, dists, idx);
+    } else {
+        hipLaunchKernelGGL(k_grid_reset_unresolved, dim3(1), dim3(1), 0, st, g.gi);
+        grid_query(p1, n1, g, dists, idx, st, 0, ref_points, warm_idx);
+    }
     E2E_LAUNCH_CHECK("e2e_knn1_index_query_dev_res");
     return E2E_OK;
 }

@@ -372,3 +372,33 @@ def test_chamfer_bidirectional_and_colour_loss_values_vs_oracle():
     torch.testing.assert_close(torch.autograd.grad(c_gpu, cg)[0].cpu(), torch.autograd.grad(c_ref, c)[0], rtol=1e-6, atol=1e-12)
     with pytest.raises(ValueError):
         color_points_loss(ct.to(DEV)[..., :2], cg, i_gpu)
+
+
+@pytest.mark.parametrize("cells", [16, 128])
+def test_resolution_parameterised_index_is_exact(cells):
+    """e2e_knn1_index_*_res (the odometry's index: caller-chosen cells per axis, a wave per query for small query sets, cold and
+    warm-started): distances and indices equal the brute force bit for bit -- near queries, queries far outside the cloud, warm
+    candidates that are right, random, out of range and negative."""
+    from e2ehip import _lib as L
+    from e2ehip import ops
+    lib = L.load()
+    g = torch.Generator().manual_seed(77 + cells)
+    n2, cap, n1 = 40000, 65536, 6000
+    ref = torch.zeros(cap, 3)
+    ref[:n2] = torch.rand(n2, 3, generator=g) * torch.tensor([4.0, 3.0, 0.2])            # a slab-like cloud
+    q = torch.cat([ref[torch.randint(0, n2, (n1 // 2,), generator=g)] + 0.01 * torch.randn(n1 // 2, 3, generator=g),
+                   torch.rand(n1 // 2, 3, generator=g) * 6.0 - 1.0])                       # half near the cloud, half anywhere (some far outside)
+    refd, qd = ref.to(DEV), q.to(DEV).contiguous()
+    count = torch.tensor([n2, 0, 0], device=DEV, dtype=torch.int64)
+    index = torch.empty(lib.e2e_knn1_index_capacity_bytes_res(n1, cap, cells), device=DEV, dtype=torch.uint8)
+    L.call("e2e_knn1_index_build_dev_res", L.ptr(refd), L.ptr(count), cap, n1, L.ptr(index), cells, L.stream())
+    d_ref, i_ref = ops.knn1(qd, refd[:n2].contiguous(), algorithm="brute")
+    d, i = torch.empty(n1, device=DEV), torch.empty(n1, device=DEV, dtype=torch.int64)
+    L.call("e2e_knn1_index_query_dev_res", L.ptr(qd), n1, None, None, cap, n1, L.ptr(index), cells, L.ptr(d), L.ptr(i), L.stream())
+    assert torch.equal(i, i_ref) and torch.equal(d, d_ref)
+    for name, warm in (("true", i_ref.clone()), ("random", torch.randint(0, n2, (n1,), generator=g).to(DEV)),
+                       ("mixed", torch.where(torch.arange(n1, device=DEV) % 3 == 0, torch.full((n1,), -1, device=DEV), torch.full((n1,), n2 + 5, device=DEV)))):
+        warm = warm.to(torch.int64).contiguous()
+        d2, i2 = torch.full((n1,), -1.0, device=DEV), warm.clone()                                  # idx aliases the warm buffer, as the odometry does
+        L.call("e2e_knn1_index_query_dev_res", L.ptr(qd), n1, L.ptr(refd), L.ptr(i2), cap, n1, L.ptr(index), cells, L.ptr(d2), L.ptr(i2), L.stream())
+        assert torch.equal(i2, i_ref) and torch.equal(d2, d_ref), name
