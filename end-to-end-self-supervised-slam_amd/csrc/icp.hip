@@ -140,9 +140,23 @@ __global__ void k_icp_init(double* state, float* T32, float* step32, const float
 }
 
 // mode 0 = icp (phase 0 only), 1 = gradicp (phase 0: solve + trial step; phase 1: damping update from the trial step's error, gated step)
-__global__ void k_icp_update(const double* __restrict__ out29, double* __restrict__ state, float* __restrict__ T32, float* __restrict__ step32,
+// partials != NULL: the 29 sums are first folded from the workgroup partials of k_icp_partials (thread k < 29 adds its accumulator's
+// nparts values in index order) -- one launch less per reduction than k_icp_final + k_icp_update
+__global__ __launch_bounds__(64) void k_icp_update(const double* __restrict__ out29_in, const double* __restrict__ partials, int nparts,
+                             double* __restrict__ state, float* __restrict__ T32, float* __restrict__ step32,
                              const float* __restrict__ prev_pose, float* __restrict__ pose_out, int mode, int phase, double lambda_max,
                              double B, double B2, double nu) {
+    __shared__ double sums[ICP_NACC];
+    const double* out29 = out29_in;
+    if (partials) {
+        if (threadIdx.x < ICP_NACC) {
+            double s = 0.0;
+            for (int i = 0; i < nparts; ++i) s += partials[(int64_t)i * ICP_NACC + threadIdx.x];
+            sums[threadIdx.x] = s;
+        }
+        __syncthreads();
+        out29 = sums;
+    }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (state[24] != 0.0) return;                          // stopped (fewer than 6 inliers at some iteration): the pose stays
     const double cnt = out29[27], err = out29[28];
@@ -214,7 +228,8 @@ int e2e_icp_update(const double* out29, double* state, float* T32, float* step32
                    double lambda_max, double B, double B2, double nu, void* stream) {
     E2E_REQUIRE(out29 && state && T32 && step32 && (!pose_out || prev_pose), E2E_ERR_ARG, "e2e_icp_update: null pointer");
     E2E_REQUIRE((mode == 0 && phase == 0) || (mode == 1 && (phase == 0 || phase == 1)), E2E_ERR_ARG, "e2e_icp_update: mode 0 (icp, phase 0) or 1 (gradicp, phase 0 / 1)");
-    hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, (hipStream_t)stream, out29, state, T32, step32, prev_pose, pose_out, mode, phase, lambda_max, B, B2, nu);
+    hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, (hipStream_t)stream, out29, (const double*)nullptr, 0, state, T32, step32, prev_pose, pose_out, mode,
+                       phase, lambda_max, B, B2, nu);
     E2E_LAUNCH_CHECK("e2e_icp_update");
     return E2E_OK;
 }
@@ -241,6 +256,25 @@ int e2e_icp_normal_equations(const float* src, const float* tgt, const float* tg
                        dist_thresh < 0.f ? -1.f : dist_thresh * dist_thresh, n, (double*)workspace);
     hipLaunchKernelGGL(k_icp_final, dim3(ICP_NACC), dim3(64), 0, st, (const double*)workspace, g, out29);
     E2E_LAUNCH_CHECK("e2e_icp_normal_equations");
+    return E2E_OK;
+}
+
+/* e2e_icp_normal_equations + e2e_icp_update in two launches instead of three: the update kernel folds the workgroup partials itself. */
+int e2e_icp_reduce_update(const float* src, const float* tgt, const float* tgt_normals, const long long* idx, const float* dists, float dist_thresh,
+                          int64_t n, void* workspace, double* state, float* T32, float* step32, const float* prev_pose, float* pose_out, int mode,
+                          int phase, double lambda_max, double B, double B2, double nu, void* stream) {
+    E2E_REQUIRE(src && tgt && tgt_normals && idx && workspace && state && T32 && step32 && n > 0 && (!pose_out || prev_pose), E2E_ERR_ARG,
+                "e2e_icp_reduce_update: bad argument");
+    E2E_REQUIRE(dist_thresh < 0.f || dists, E2E_ERR_ARG, "e2e_icp_reduce_update: a distance threshold needs the distances");
+    E2E_REQUIRE((mode == 0 && phase == 0) || (mode == 1 && (phase == 0 || phase == 1)), E2E_ERR_ARG, "e2e_icp_reduce_update: mode 0 (icp, phase 0) or 1 (gradicp, phase 0 / 1)");
+    hipStream_t st = (hipStream_t)stream;
+    int g = (int)((n + ICP_T - 1) / ICP_T);
+    if (g > ICP_MAX_PARTS) g = ICP_MAX_PARTS;
+    hipLaunchKernelGGL(k_icp_partials, dim3(g), dim3(ICP_T), 0, st, src, tgt, tgt_normals, idx, dists, dist_thresh < 0.f ? -1.f : dist_thresh * dist_thresh, n,
+                       (double*)workspace);
+    hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(64), 0, st, (const double*)nullptr, (const double*)workspace, g, state, T32, step32, prev_pose, pose_out, mode,
+                       phase, lambda_max, B, B2, nu);
+    E2E_LAUNCH_CHECK("e2e_icp_reduce_update");
     return E2E_OK;
 }
 

@@ -140,6 +140,8 @@ SIGNATURES = {
     "e2e_icp_state_doubles": [],
     "e2e_icp_state_init": [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_double, c_fp],
     "e2e_icp_update": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_fp],
+    "e2e_icp_reduce_update": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f32, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int,
+                              ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_fp],
     "e2e_icp_source_subsample": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "e2e_pf_active_subsample_dev": [c_fp, c_fp, c_fp, c_i64, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_i64, c_fp],
     "e2e_icp_normal_equations": [c_fp, c_fp, c_fp, c_fp, c_fp, c_f32, c_i64, c_fp, c_fp, c_fp],

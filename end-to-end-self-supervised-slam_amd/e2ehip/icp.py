@@ -108,7 +108,7 @@ class ResidentOdometry:
     check() together with the target-capacity overflow flag wherever the host synchronises anyway."""
 
     def __init__(self, fmap, dsratio=4, numiters=20, mode="gradicp", damp=1e-8, dist_thresh=None, lambda_max=2.0, B=1.0, B2=1.0, nu=200.0,
-                 target_capacity=None, grid_cells=128):
+                 target_capacity=None, grid_cells=256):
         if mode not in ("icp", "gradicp"):
             raise ValueError(f"unknown odometry mode {mode}")
         self.map, self.ds, self.numiters, self.mode = fmap, int(dsratio), int(numiters), mode
@@ -139,14 +139,14 @@ class ResidentOdometry:
         from .ops import fusion_alpha_den
         self._alpha_den = float(fusion_alpha_den(fmap.sigma))
 
-    def _reduce(self, pts, st, warm):
-        # from the second search of a keyframe on, the previous search's neighbours (same source points, moved by one small step; same
-        # targets) bound the search from the start: a lane then visits the few cells inside that ball instead of walking three shells of a
-        # sparse grid -- with 19 200 queries there are too few waves to hide that walk's latency (86 + 72 us per cold search, 40 per keyframe)
+    def _search_reduce_update(self, pts, st, warm, phase, prev_pose):
+        # every search after the first of a keyframe starts from the previous search's neighbours (same source points, moved by one small
+        # step; same targets): a real target point's distance bounds the ball from the start -- exact for any candidate
         L.call("e2e_knn1_index_query_dev_res", L.ptr(pts), self.n_src, L.ptr(self.tgt) if warm else None, L.ptr(self.idx) if warm else None, self.tcap,
                self.n_src, L.ptr(self.index), self.cells, L.ptr(self.d), L.ptr(self.idx), st)
-        L.call("e2e_icp_normal_equations", L.ptr(pts), L.ptr(self.tgt), L.ptr(self.tgt_n), L.ptr(self.idx), L.ptr(self.d),
-               -1.0 if self.dist_thresh is None else float(self.dist_thresh), self.n_src, L.ptr(self.out29), L.ptr(self.ws), st)
+        L.call("e2e_icp_reduce_update", L.ptr(pts), L.ptr(self.tgt), L.ptr(self.tgt_n), L.ptr(self.idx), L.ptr(self.d),
+               -1.0 if self.dist_thresh is None else float(self.dist_thresh), self.n_src, L.ptr(self.ws), L.ptr(self.state), L.ptr(self.T32),
+               L.ptr(self.step32), L.ptr(prev_pose), L.ptr(self.pose), 1 if self.mode == "gradicp" else 0, phase, *self.lm, st)
 
     def run(self, depth, K, prev_pose):
         """depth (H,W) of the live frame, K (4,4), prev_pose (4,4): contiguous device tensors (resident buffers when this is captured).
@@ -166,17 +166,12 @@ class ResidentOdometry:
         L.call("e2e_icp_source_subsample", L.ptr(self.Vg), L.ptr(depth), H, W, self.ds, L.ptr(self.src), L.ptr(self.status), st)
         L.call("e2e_knn1_index_build_dev_res", L.ptr(self.tgt), L.ptr(self.tcount), self.tcap, self.n_src, L.ptr(self.index), self.cells, st)
         L.call("e2e_icp_state_init", L.ptr(self.state), L.ptr(self.T32), L.ptr(self.step32), L.ptr(prev_pose), L.ptr(self.pose), self.damp, st)
-        mode = 1 if self.mode == "gradicp" else 0
         for it in range(self.numiters):
             L.call("e2e_transform_points", L.ptr(self.src), L.ptr(self.T32), L.ptr(self.cur), self.n_src, 0, st)
-            self._reduce(self.cur, st, warm=it > 0)
-            L.call("e2e_icp_update", L.ptr(self.out29), L.ptr(self.state), L.ptr(self.T32), L.ptr(self.step32), L.ptr(prev_pose), L.ptr(self.pose),
-                   mode, 0, *self.lm, st)
-            if mode == 1:
+            self._search_reduce_update(self.cur, st, it > 0, 0, prev_pose)
+            if self.mode == "gradicp":
                 L.call("e2e_transform_points", L.ptr(self.cur), L.ptr(self.step32), L.ptr(self.nxt), self.n_src, 0, st)
-                self._reduce(self.nxt, st, warm=True)
-                L.call("e2e_icp_update", L.ptr(self.out29), L.ptr(self.state), L.ptr(self.T32), L.ptr(self.step32), L.ptr(prev_pose), L.ptr(self.pose),
-                       mode, 1, *self.lm, st)
+                self._search_reduce_update(self.nxt, st, True, 1, prev_pose)
         m._assoc_M = None
         return self.pose
 

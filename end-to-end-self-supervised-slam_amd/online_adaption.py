@@ -335,7 +335,7 @@ class SLAM:
         if getattr(self, "_odo", None) is None:
             from e2ehip.icp import ResidentOdometry
             self._odo = ResidentOdometry(self.map, dsratio=4, numiters=self.args.MODEL.numiters, mode=self.args.MODEL.odom,
-                                         grid_cells=int(os.environ.get("E2E_ICP_CELLS", "128")))
+                                         grid_cells=int(os.environ.get("E2E_ICP_CELLS", "256")))
         return self._odo
 
     def _log_step(self, rec, refine_step, nsteps):

@@ -610,6 +610,11 @@ int e2e_icp_state_init(double* state, float* T32, float* step32, const float* pr
 int e2e_icp_update(const double* out29, double* state, float* T32, float* step32, const float* prev_pose,
                    float* pose_out, int mode, int phase, double lambda_max, double B, double B2, double nu,
                    void* stream);
+/* e2e_icp_normal_equations followed by e2e_icp_update as TWO launches (the update folds the per-workgroup partial sums itself). */
+int e2e_icp_reduce_update(const float* src, const float* tgt, const float* tgt_normals, const long long* idx,
+                          const float* dists, float dist_thresh, int64_t n, void* workspace, double* state, float* T32,
+                          float* step32, const float* prev_pose, float* pose_out, int mode, int phase,
+                          double lambda_max, double B, double B2, double nu, void* stream);
 /* Source cloud of the odometry (gradslam downsample_rgbdimages): every dsratio-th pixel in both directions of the live
  * frame's world vertex map Vg (H,W,3), row-major -> src (ceil(H/ds) * ceil(W/ds), 3).  A selected pixel without depth sets
  * *status (device int32; the resident path serves network-predicted depths, which are positive everywhere). */
