@@ -140,8 +140,8 @@ __global__ void k_icp_init(double* state, float* T32, float* step32, const float
 }
 
 // mode 0 = icp (phase 0 only), 1 = gradicp (phase 0: solve + trial step; phase 1: damping update from the trial step's error, gated step)
-// partials != NULL: the 29 sums are first folded from the workgroup partials of k_icp_partials (thread k < 29 adds its accumulator's
-// nparts values in index order) -- one launch less per reduction than k_icp_final + k_icp_update
+// partials != NULL: the 29 sums are first folded from the workgroup partials of k_icp_partials (by the whole wave, as k_icp_final does)
+// -- one launch less per reduction than k_icp_final + k_icp_update
 __global__ __launch_bounds__(64) void k_icp_update(const double* __restrict__ out29_in, const double* __restrict__ partials, int nparts,
                              double* __restrict__ state, float* __restrict__ T32, float* __restrict__ step32,
                              const float* __restrict__ prev_pose, float* __restrict__ pose_out, int mode, int phase, double lambda_max,
@@ -149,10 +149,11 @@ __global__ __launch_bounds__(64) void k_icp_update(const double* __restrict__ ou
     __shared__ double sums[ICP_NACC];
     const double* out29 = out29_in;
     if (partials) {
-        if (threadIdx.x < ICP_NACC) {
-            double s = 0.0;
-            for (int i = 0; i < nparts; ++i) s += partials[(int64_t)i * ICP_NACC + threadIdx.x];
-            sums[threadIdx.x] = s;
+        for (int k = 0; k < ICP_NACC; ++k) {               // the wave folds one accumulator at a time: lane l adds partials l, l + 64, ..., then a fixed tree
+            double v = 0.0;
+            for (int i = threadIdx.x; i < nparts; i += 64) v += partials[(int64_t)i * ICP_NACC + k];
+            v = wave_sum_d(v);
+            if (threadIdx.x == 0) sums[k] = v;
         }
         __syncthreads();
         out29 = sums;
