@@ -14,7 +14,7 @@ __global__ __launch_bounds__(ICP_T) void k_icp_partials(const float* __restrict_
                                                         const float* __restrict__ tgt_n, const long long* __restrict__ idx,
                                                         const float* __restrict__ dists, float thresh_sq, int64_t n,
                                                         double* __restrict__ partials) {
-    __shared__ double sh[ICP_T / 64];
+    __shared__ double sh[ICP_NACC][ICP_T / 64];
     double acc[ICP_NACC];
 #pragma unroll
     for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
@@ -36,13 +36,13 @@ __global__ __launch_bounds__(ICP_T) void k_icp_partials(const float* __restrict_
         acc[27] += 1.0;
         acc[28] += b * b;
     }
+#pragma unroll
     for (int k = 0; k < ICP_NACC; ++k) {
         const double v = wave_sum_d(acc[k]);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) partials[(int64_t)blockIdx.x * ICP_NACC + k] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+        if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = v;
     }
+    __syncthreads();                                           // ONE barrier for the 29 sums (round 3: two per sum)
+    if (threadIdx.x < ICP_NACC) partials[(int64_t)blockIdx.x * ICP_NACC + threadIdx.x] = ((sh[threadIdx.x][0] + sh[threadIdx.x][1]) + sh[threadIdx.x][2]) + sh[threadIdx.x][3];
 }
 
 // one wave per accumulator: lane l adds the partials l, l + 64, ... in order, then a fixed shuffle tree (reproducible; a single thread
