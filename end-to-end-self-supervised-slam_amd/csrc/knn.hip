@@ -121,7 +121,6 @@ static inline int64_t grid_cells_cap(int64_t n2) { const int64_t g = grid_max_fo
 #define GRID_RMAX 3      // shells of the one-query-per-lane pass; whatever it cannot bound goes to the wave-per-query pass
                          // (2: 130 + 158 us, 3: 180 + 52 us, 4: 282 + 45 us on the 256^3 grid)
 #define SCAN_BLOCK 1024
-#define ROWOCC_WORDS (GRID_MAX_BIG * GRID_MAX_BIG / 32)     // one bit per (cz, cy) cell row: does the row hold any point?
 
 struct GridInfo {
     unsigned int bb[6];        // order-preserving keys of min xyz, max xyz
@@ -311,20 +310,6 @@ __global__ __launch_bounds__(KT) void k_scan_apply(const unsigned int* __restric
     }
 }
 
-// Row occupancy: bit (cz * dims[1] + cy) is set when the cell row holds at least one point.  A map is a surface: most rows inside a search
-// ball are empty, and a query that skips them by a cached bit saves the two dependent `starts` loads each would cost (round 4).
-__global__ __launch_bounds__(256) void k_grid_rowocc(const GridInfo* __restrict__ gi, const unsigned int* __restrict__ starts, unsigned int* __restrict__ rowocc) {
-    const int d0 = gi->dims[0], nrows = gi->dims[1] * gi->dims[2];
-    const int w = blockIdx.x * 256 + threadIdx.x;
-    if (w >= ROWOCC_WORDS) return;
-    unsigned int bits = 0;
-    for (int b = 0; b < 32; ++b) {
-        const int r = w * 32 + b;
-        if (r < nrows && starts[(unsigned int)(r + 1) * d0] != starts[(unsigned int)r * d0]) bits |= 1u << b;
-    }
-    rowocc[w] = bits;
-}
-
 __global__ __launch_bounds__(KT) void k_grid_scatter(const float* __restrict__ p, int64_t n, const long long* __restrict__ nptr, const unsigned int* __restrict__ cell_of,
                                                      const unsigned int* __restrict__ starts, unsigned int* __restrict__ fill,
                                                      float4* __restrict__ sorted) {
@@ -348,8 +333,7 @@ __global__ __launch_bounds__(KT) void k_grid_scatter(const float* __restrict__ p
 __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1, int64_t n1, int row_len, GridInfo* __restrict__ gi,
                                                    const unsigned int* __restrict__ starts, const float4* __restrict__ sorted,
                                                    float* __restrict__ dists, long long* idx,
-                                                   unsigned int* __restrict__ unresolved, const float* __restrict__ ref, const long long* warm,
-                                                   const unsigned int* __restrict__ rowocc) {
+                                                   unsigned int* __restrict__ unresolved, const float* __restrict__ ref, const long long* warm) {
     int64_t i0 = (int64_t)blockIdx.x * KT + threadIdx.x;
     if (row_len > 0) {
         const int64_t tile = i0 >> 6;
@@ -397,8 +381,6 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
                 const float gys = fmaxf(gy * 0.999f - eps, 0.f);
                 const float dyz = gzs * gzs + gys * gys;
                 if (dyz > bd) continue;
-                const unsigned int rowid = (unsigned int)(cz * dims[1] + cy);
-                if (!((rowocc[rowid >> 5] >> (rowid & 31u)) & 1u)) continue;      // an empty row (most rows around a surface are)
                 // cells of one (cz,cy) row are consecutive => their points form ONE contiguous range of `sorted`.
                 // A row that was already inside the previous cube only contributes its two new end segments.
                 const bool row_in_prev = cz >= pl[2] && cz <= ph[2] && cy >= pl[1] && cy <= ph[1];
@@ -475,8 +457,7 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
 // case every point of the grid is visited once -- the brute force this replaces read all n2 points per query.
 __global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, const GridInfo* __restrict__ gi,
                                                   const unsigned int* __restrict__ starts, const float4* __restrict__ sorted,
-                                                  const unsigned int* __restrict__ unresolved, float* dists, long long* idx,
-                                                  const unsigned int* __restrict__ rowocc) {
+                                                  const unsigned int* __restrict__ unresolved, float* dists, long long* idx) {
     const unsigned int cnt = gi->n_unresolved;
     const int lane = threadIdx.x & 63;
     const unsigned int wave0 = blockIdx.x * (KT / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (KT / 64);
@@ -506,8 +487,6 @@ __global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, 
             const float bd0 = __uint_as_float((unsigned int)(best >> 32));   // wave-uniform bound from the previous shells
             for (int t = lane; t < nrows; t += 64) {
                 const int cz = lo[2] + t / ny, cy = lo[1] + t % ny;
-                const unsigned int rowid = (unsigned int)(cz * dims[1] + cy);
-                if (!((rowocc[rowid >> 5] >> (rowid & 31u)) & 1u)) continue;      // an empty row
                 const bool row_in_prev = cz >= pl[2] && cz <= ph[2] && cy >= pl[1] && cy <= ph[1];
                 const unsigned int rowbase = (unsigned int)((cz * dims[1] + cy) * dims[0]);
                 int seg_lo[2] = {lo[0], 0}, seg_hi[2] = {hi[0], -1};
@@ -600,7 +579,7 @@ static int64_t grid_ws_bytes(int64_t n1, int64_t n2, bool big_always = false, in
     const int64_t nc = cells > 0 ? (int64_t)cells * cells * cells : (big_always ? (int64_t)GRID_MAX_BIG * GRID_MAX_BIG * GRID_MAX_BIG : grid_cells_cap(n2)),
                   nb = (nc + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
     // GridInfo | counts[nc+1] | starts[nc+1] | fill[nc] | bsum[nb] | cell_of[n2] | unresolved[n1] | sorted float4[n2]
-    return 256 + 4 * (nc + 1) * 2 + 4 * nc + 4 * (nb + 1) + 4 * 6 * BBOX_BLOCKS + 4 * ROWOCC_WORDS + 4 * n2 + 4 * n1 + 64 + 16 * n2;
+    return 256 + 4 * (nc + 1) * 2 + 4 * nc + 4 * (nb + 1) + 4 * 6 * BBOX_BLOCKS + 4 * n2 + 4 * n1 + 64 + 16 * n2;
 }
 
 int64_t e2e_knn1_workspace_bytes(int64_t n1, int64_t n2) {
@@ -612,7 +591,7 @@ int64_t e2e_knn1_workspace_bytes(int64_t n1, int64_t n2) {
 
 struct GridWs {
     GridInfo* gi;
-    unsigned int *counts, *starts, *fill, *bsum, *bbpart, *cell_of, *unresolved, *rowocc;
+    unsigned int *counts, *starts, *fill, *bsum, *bbpart, *cell_of, *unresolved;
     float4* sorted;
     int64_t nc;
     int nb;
@@ -631,7 +610,6 @@ static GridWs grid_ws(void* workspace, int64_t nq, int64_t n2, bool big_always =
     g.fill = (unsigned int*)w; w += 4 * g.nc;
     g.bsum = (unsigned int*)w; w += 4 * (g.nb + 1);
     g.bbpart = (unsigned int*)w; w += 4 * 6 * BBOX_BLOCKS;
-    g.rowocc = (unsigned int*)w; w += 4 * ROWOCC_WORDS;
     g.cell_of = (unsigned int*)w; w += 4 * n2;
     g.unresolved = (unsigned int*)w; w += 4 * nq;
     w = (char*)(((uintptr_t)w + 63) & ~(uintptr_t)63);
@@ -653,7 +631,6 @@ static void grid_build(const float* p2, int64_t n2, const long long* n2_dev, con
     hipLaunchKernelGGL(k_scan_blocksum, dim3(g.nb), dim3(KT), 0, st, g.counts, nscan, g.bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, g.bsum, g.nb);
     hipLaunchKernelGGL(k_scan_apply, dim3(g.nb), dim3(KT), 0, st, g.counts, nscan, g.bsum, g.starts);
-    hipLaunchKernelGGL(k_grid_rowocc, dim3(ROWOCC_WORDS / 256), dim3(256), 0, st, g.gi, g.starts, g.rowocc);
     hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(KT), 0, st, p2, n2, n2_dev, g.cell_of, g.starts, g.fill, g.sorted);
 }
 
@@ -662,13 +639,13 @@ static void grid_query(const float* p1, int64_t n1, const GridWs& g, float* dist
     if (row_len <= 0 || (row_len & 7) || n1 % ((int64_t)row_len * 8)) row_len = 0;      // tile order needs whole 8 x 8 tiles
     if (!ref) warm = nullptr;
     hipLaunchKernelGGL(k_grid_query, dim3((unsigned)((n1 + KT - 1) / KT)), dim3(KT), 0, st, p1, n1, row_len, g.gi, g.starts, g.sorted, dists, idx, g.unresolved, ref,
-                       warm, g.rowocc);
+                       warm);
     // one WAVE per unresolved query: 1024 workgroups (4096 waves) suit the refinement queries, of which a few per cent stay unresolved; a small
     // query set that is mostly unresolved (frame-to-model odometry while the pose is still wrong: 19 200 queries, decimetres off the targets)
     // gets a wave per query instead of 2-5 queries per wave in sequence -- idle workgroups leave at once
     const int64_t rest_blocks = n1 <= 65536 ? (n1 + 3) / 4 : 1024;
     hipLaunchKernelGGL(k_knn1_rest, dim3((unsigned)(rest_blocks < 1024 ? 1024 : (rest_blocks > 8192 ? 8192 : rest_blocks))), dim3(KT), 0, st, p1, g.gi, g.starts,
-                       g.sorted, g.unresolved, dists, idx, g.rowocc);
+                       g.sorted, g.unresolved, dists, idx);
 }
 
 static int knn1_grid(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists, long long* idx, void* workspace, hipStream_t st) {
@@ -764,7 +741,7 @@ int e2e_knn1_index_query_dev_res(const float* p1, int64_t n1, const float* ref_p
     hipStream_t st = (hipStream_t)stream;
     if (n1 <= 32768) {                                          // a wave per query from the start (see k_knn1_all_unresolved)
         hipLaunchKernelGGL(k_knn1_all_unresolved, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, p1, n1, g.gi, g.unresolved, ref_points, warm_idx, dists, idx);
-        hipLaunchKernelGGL(k_knn1_rest, dim3((unsigned)((n1 + 3) / 4)), dim3(KT), 0, st, p1, g.gi, g.starts, g.sorted, g.unresolved, dists, idx, g.rowocc);
+        hipLaunchKernelGGL(k_knn1_rest, dim3((unsigned)((n1 + 3) / 4)), dim3(KT), 0, st, p1, g.gi, g.starts, g.sorted, g.unresolved, dists, idx);
     } else {
         hipLaunchKernelGGL(k_grid_reset_unresolved, dim3(1), dim3(1), 0, st, g.gi);
         grid_query(p1, n1, g, dists, idx, st, 0, ref_points, warm_idx);
