@@ -42,6 +42,10 @@ print(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 60
 for r in rows[:70]:
     print(f"{r['Name'][:90]:90s} calls {r['Calls']:>6s} avg_us {float(r['AverageNs'])/1e3:9.1f} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} {100*float(r['TotalDurationNs'])/tot:5.1f}%")
 PY
+# are the ATen fill launches of the trace per step or start-up?  the same trace over 9 instead of 65 steps: an equal count = allocation-time zero fills
+rocprofv3 --kernel-trace --stats -d /tmp/ev2_$TAG -o short --output-format csv -- python3 bench.py --gpus 1 --steps 6 --warmup 3 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/rocprof_short.err
+f2=$(find /tmp/ev2_$TAG -name "*kernel_stats.csv" | head -1)
+{ echo "FillFunctor launches, bench.py --steps 60 --warmup 5 (65 steps):"; grep -i "FillFunctor" "$f" | cut -d, -f1-3 | cut -c1-160; echo "FillFunctor launches, bench.py --steps 6 --warmup 3 (9 steps):"; grep -i "FillFunctor" "$f2" | cut -d, -f1-3 | cut -c1-160; } > $OUT/fill_launches.txt
 fi
 if [ "$PART" != "bench" ]; then
 timeout -k 10 500 python3 tools/gemm_tune.py both > $OUT/gemm_tune.txt 2>&1; echo "tune $?" >> $OUT/progress.txt
