@@ -2,6 +2,7 @@
 # usage: tools/evidence.sh <tag>  -- the measured evidence of a round, under gpurun_out/evidence_<tag>/ (copy what is to be judged to profiles/):
 #   bench_default.json          python3 bench.py --gpus 1 --steps 20 --warmup 5                      (the driver's command)
 #   bench_fullpass.json         ... --steps 177 --warmup 6: one whole pass of the 60-frame sequence (59 keyframes x 3 steps)
+#   bench_tum.json              ... --tum: BASELINE configs[3] (TUM intrinsics, 10 % depth holes, threshold 0.12)
 #   bench_gradicp.json          ... --odom gradicp: frame-to-model GradICP odometry in the map step, reports the ATE
 #   bench_overlap.json          E2E_WGRAD_OVERLAP=1: backward-weight chains on a second stream (A/B of the one-stream default)
 #   kernel_stats.txt, timeline.txt   rocprofv3 --kernel-trace --stats of `bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-roofline`
@@ -27,6 +28,7 @@ echo "pmc done" > $OUT/progress.txt
 python3 bench.py --gpus 1 --steps 177 --warmup 6 --no-cpu-baseline > $OUT/bench_fullpass.json 2> $OUT/bench_fullpass.err; echo "fullpass $?" >> $OUT/progress.txt
 cp $OUT/bench_fullpass.json profiles/r04_bench_seq_fullpass.json
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default $?" >> $OUT/progress.txt
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --tum --no-cpu-baseline --no-roofline > $OUT/bench_tum.json 2> $OUT/bench_tum.err; echo "tum $?" >> $OUT/progress.txt
 E2E_WGRAD_OVERLAP=1 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/bench_overlap.json 2> $OUT/bench_overlap.err; echo "overlap $?" >> $OUT/progress.txt
 timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-roofline --odom gradicp > $OUT/bench_gradicp.json 2> $OUT/bench_gradicp.err; echo "gradicp $?" >> $OUT/progress.txt
 rocprofv3 --kernel-trace --stats -d /tmp/ev_$TAG -o full --output-format csv -- python3 bench.py --gpus 1 --steps 60 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
