@@ -44,12 +44,22 @@ print(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 60
 for r in rows[:70]:
     print(f"{r['Name'][:90]:90s} calls {r['Calls']:>6s} avg_us {float(r['AverageNs'])/1e3:9.1f} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} {100*float(r['TotalDurationNs'])/tot:5.1f}%")
 PY
-# are the ATen fill launches of the trace per step or start-up?  the same trace over 9 instead of 65 steps: an equal count = allocation-time zero fills
-rocprofv3 --kernel-trace --stats -d /tmp/ev2_$TAG -o short --output-format csv -- python3 bench.py --gpus 1 --steps 6 --warmup 3 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/rocprof_short.err
-f2=$(find /tmp/ev2_$TAG -name "*kernel_stats.csv" | head -1)
-{ echo "FillFunctor launches, bench.py --steps 60 --warmup 5 (65 steps):"; grep -i "FillFunctor" "$f" | cut -d, -f1-3 | cut -c1-160; echo "FillFunctor launches, bench.py --steps 6 --warmup 3 (9 steps):"; grep -i "FillFunctor" "$f2" | cut -d, -f1-3 | cut -c1-160; } > $OUT/fill_launches.txt
 fi
 if [ "$PART" != "bench" ]; then
+# are the ATen fill launches of the kernel trace per step or start-up?  the same trace over 9 and over 65 steps: equal counts = allocation-time zero fills
+for n in 6 60; do
+  rocprofv3 --kernel-trace --stats -d /tmp/evf_${TAG}_$n -o t --output-format csv -- python3 bench.py --gpus 1 --steps $n --warmup 3 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/rocprof_fill_$n.err
+done
+python3 - /tmp/evf_${TAG}_6 /tmp/evf_${TAG}_60 > $OUT/fill_launches.txt <<'PY'
+import csv, glob, sys
+for d, steps in ((sys.argv[1], 9), (sys.argv[2], 63)):
+    f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(f)) if "FillFunctor" in r["Name"]]
+    print(f"bench.py --steps {steps - 3} --warmup 3 ({steps} refinement steps): {sum(int(r['Calls']) for r in rows)} FillFunctor launches, {sum(float(r['TotalDurationNs']) for r in rows) / 1e3:.0f} us in total")
+    for r in rows:
+        print(f"    {r['Calls']:>5s} x {r['Name'][:110]}")
+PY
+echo "fills done" >> $OUT/progress.txt
 timeout -k 10 500 python3 tools/gemm_tune.py both > $OUT/gemm_tune.txt 2>&1; echo "tune $?" >> $OUT/progress.txt
 timeout -k 10 300 python3 tools/pass_profile.py > $OUT/pass_profile.txt 2> $OUT/pass_profile.err; echo "pass profile $?" >> $OUT/progress.txt
 if [ -f scratch/_stamped/libe2eslam_hip_stamped.so ]; then python3 scratch/conv_stamps.py 2>&1 | grep -v amdgpu.ids > $OUT/conv_stamps.txt; echo "stamps $?" >> $OUT/progress.txt; fi
