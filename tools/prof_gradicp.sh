@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/prof_gradicp.sh <tag>  -- per-kernel time of bench.py --odom gradicp (rocprofv3 --kernel-trace --stats) + the pass profile with GC / device-time columns
+# usage: tools/prof_gradicp.sh <tag>  -- per-kernel time of bench.py --odom gradicp (rocprofv3 --kernel-trace --stats)
 export TMPDIR=/tmp
 TAG=$1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/gradicp_$TAG; mkdir -p $OUT
@@ -14,7 +14,4 @@ print(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup
 for r in rows[:45]:
     print(f"{r['Name'][:90]:90s} calls {r['Calls']:>6s} avg_us {float(r['AverageNs'])/1e3:9.1f} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} {100*float(r['TotalDurationNs'])/tot:5.1f}%")
 PY
-echo "rocprof done" > $OUT/progress.txt
-timeout -k 10 300 python3 tools/pass_profile.py --probe "" > $OUT/pass_profile_default.txt 2> $OUT/pp1.err; echo "pp default $?" >> $OUT/progress.txt
-timeout -k 10 300 python3 tools/pass_profile.py --probe "" --gc freeze > $OUT/pass_profile_freeze.txt 2> $OUT/pp2.err; echo "pp freeze $?" >> $OUT/progress.txt
-head -30 $OUT/kernel_stats.txt; grep -E "gc|wall +[2-9][0-9]\." $OUT/pass_profile_default.txt | head -20; echo ---; grep -E "gc|wall +[2-9][0-9]\." $OUT/pass_profile_freeze.txt | head
+grep -E "knn|icp|grid|transform|pf_|vertex|active|gather_active|scan|cp_count" $OUT/kernel_stats.txt | cut -c1-170
