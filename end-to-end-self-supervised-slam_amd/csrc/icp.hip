@@ -149,11 +149,17 @@ __global__ __launch_bounds__(64) void k_icp_update(const double* __restrict__ ou
     __shared__ double sums[ICP_NACC];
     const double* out29 = out29_in;
     if (partials) {
-        for (int k = 0; k < ICP_NACC; ++k) {               // the wave folds one accumulator at a time: lane l adds partials l, l + 64, ..., then a fixed tree
-            double v = 0.0;
-            for (int i = threadIdx.x; i < nparts; i += 64) v += partials[(int64_t)i * ICP_NACC + k];
-            v = wave_sum_d(v);
-            if (threadIdx.x == 0) sums[k] = v;
+        double v[ICP_NACC];                                 // lane l adds the rows l, l + 64, ... of all 29 accumulators (independent loads: one
+#pragma unroll                                             // accumulator at a time was 29 dependent round trips, 20 us), then 29 fixed shuffle trees
+        for (int k = 0; k < ICP_NACC; ++k) v[k] = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += 64) {
+#pragma unroll
+            for (int k = 0; k < ICP_NACC; ++k) v[k] += partials[(int64_t)i * ICP_NACC + k];
+        }
+#pragma unroll
+        for (int k = 0; k < ICP_NACC; ++k) {
+            const double t = wave_sum_d(v[k]);
+            if (threadIdx.x == 0) sums[k] = t;
         }
         __syncthreads();
         out29 = sums;
