@@ -520,37 +520,60 @@ __global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, 
             int lo[3], hi[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) { lo[c] = max(cq[c] - r, 0); hi[c] = min(cq[c] + r, dims[c] - 1); }
-            const int ny = hi[1] - lo[1] + 1, nrows = ny * (hi[2] - lo[2] + 1);
             const float bd0 = __uint_as_float((unsigned int)(best >> 32));   // wave-uniform bound from the previous shells
-            for (int t = lane; t < nrows; t += 64) {
-                const int cz = lo[2] + t / ny, cy = lo[1] + t % ny;
-                const bool row_in_prev = cz >= pl[2] && cz <= ph[2] && cy >= pl[1] && cy <= ph[1];
-                const unsigned int rowbase = (unsigned int)((cz * dims[1] + cy) * dims[0]);
-                int seg_lo[2] = {lo[0], 0}, seg_hi[2] = {hi[0], -1};
-                if (row_in_prev) { seg_hi[0] = pl[0] - 1; seg_lo[1] = ph[0] + 1; seg_hi[1] = hi[0]; }
-                int xlo = lo[0], xhi = hi[0];
-                if (best != 0xFFFFFFFFFFFFFFFFull) {           // same exact ball pruning as the per-lane pass
-                    const float gz = fmaxf(fmaxf(org[2] + (float)cz * h - z, z - (org[2] + (float)(cz + 1) * h)), 0.f);
-                    const float gy = fmaxf(fmaxf(org[1] + (float)cy * h - y, y - (org[1] + (float)(cy + 1) * h)), 0.f);
-                    const float gzs = fmaxf(gz * 0.999f - eps, 0.f), gys = fmaxf(gy * 0.999f - eps, 0.f);
-                    const float dyz = gzs * gzs + gys * gys;
-                    if (dyz > bd0) continue;
-                    const float rx = sqrtf(bd0 - dyz) * 1.001f + 2.f * eps;
-                    xlo = max(xlo, (int)floorf(fmaxf((x - rx - org[0]) * ih, -1.f)));
-                    xhi = min(xhi, (int)floorf(fminf((x + rx - org[0]) * ih, 1.0e6f)));
+            // The lanes take 4 x 4 (z, y) BLOCKS of cell rows, not rows: a block whose box lies outside the ball, or whose occupancy word has no
+            // bit inside the ball's x-extent, is dismissed with one cached 8-byte load -- a far query (radius r cells) then iterates ~r^2 / 16
+            // block tests instead of ~r^2 row tests before it reaches the few rows that hold points.  The bounds are those of the rows, taken for
+            // the block's box (a row's box lies inside it: its distance is not smaller), so nothing a row test would keep is dropped.
+            const int bzlo = lo[2] / OCC_B, bylo = lo[1] / OCC_B, nby = hi[1] / OCC_B - bylo + 1, nblk = nby * (hi[2] / OCC_B - bzlo + 1);
+            for (int tb = lane; tb < nblk; tb += 64) {
+                const int bz = bzlo + tb / nby, by = bylo + tb % nby;
+                const int cz0 = max(bz * OCC_B, lo[2]), cz1 = min(bz * OCC_B + OCC_B - 1, hi[2]);
+                const int cy0 = max(by * OCC_B, lo[1]), cy1 = min(by * OCC_B + OCC_B - 1, hi[1]);
+                int bxlo = lo[0], bxhi = hi[0];
+                if (best != 0xFFFFFFFFFFFFFFFFull) {
+                    const float gzb = fmaxf(fmaxf(org[2] + (float)cz0 * h - z, z - (org[2] + (float)(cz1 + 1) * h)), 0.f);
+                    const float gyb = fmaxf(fmaxf(org[1] + (float)cy0 * h - y, y - (org[1] + (float)(cy1 + 1) * h)), 0.f);
+                    const float gzbs = fmaxf(gzb * 0.999f - eps, 0.f), gybs = fmaxf(gyb * 0.999f - eps, 0.f);
+                    const float dyzb = gzbs * gzbs + gybs * gybs;
+                    if (dyzb > bd0) continue;
+                    const float rxb = sqrtf(bd0 - dyzb) * 1.001f + 2.f * eps;
+                    bxlo = max(bxlo, (int)floorf(fmaxf((x - rxb - org[0]) * ih, -1.f)));
+                    bxhi = min(bxhi, (int)floorf(fminf((x + rxb - org[0]) * ih, 1.0e6f)));
                 }
+                if (bxlo > bxhi) continue;
+                const unsigned long long occw = occ[bz * OCC_N + by];
+                if (!(occw & occ_range(bxlo, bxhi))) continue;
+                for (int cz = cz0; cz <= cz1; ++cz)
+                for (int cy = cy0; cy <= cy1; ++cy) {
+                    const bool row_in_prev = cz >= pl[2] && cz <= ph[2] && cy >= pl[1] && cy <= ph[1];
+                    const unsigned int rowbase = (unsigned int)((cz * dims[1] + cy) * dims[0]);
+                    int seg_lo[2] = {lo[0], 0}, seg_hi[2] = {hi[0], -1};
+                    if (row_in_prev) { seg_hi[0] = pl[0] - 1; seg_lo[1] = ph[0] + 1; seg_hi[1] = hi[0]; }
+                    int xlo = lo[0], xhi = hi[0];
+                    if (best != 0xFFFFFFFFFFFFFFFFull) {           // same exact ball pruning as the per-lane pass
+                        const float gz = fmaxf(fmaxf(org[2] + (float)cz * h - z, z - (org[2] + (float)(cz + 1) * h)), 0.f);
+                        const float gy = fmaxf(fmaxf(org[1] + (float)cy * h - y, y - (org[1] + (float)(cy + 1) * h)), 0.f);
+                        const float gzs = fmaxf(gz * 0.999f - eps, 0.f), gys = fmaxf(gy * 0.999f - eps, 0.f);
+                        const float dyz = gzs * gzs + gys * gys;
+                        if (dyz > bd0) continue;
+                        const float rx = sqrtf(bd0 - dyz) * 1.001f + 2.f * eps;
+                        xlo = max(xlo, (int)floorf(fmaxf((x - rx - org[0]) * ih, -1.f)));
+                        xhi = min(xhi, (int)floorf(fminf((x + rx - org[0]) * ih, 1.0e6f)));
+                    }
 #pragma unroll
-                for (int sgm = 0; sgm < 2; ++sgm) {
-                    const int s0 = max(seg_lo[sgm], xlo), s1 = min(seg_hi[sgm], xhi);
-                    if (s0 > s1) continue;
-                    if (!(occ[(cz / OCC_B) * OCC_N + (cy / OCC_B)] & occ_range(s0, s1))) continue;
-                    const unsigned int e = starts[rowbase + s1 + 1];
-                    for (unsigned int k = starts[rowbase + s0]; k < e; ++k) {
-                        const float4 tq = sorted[k];
-                        const float dx = x - tq.x, dy = y - tq.y, dz = z - tq.z;
-                        const float d = (dx * dx + dy * dy) + dz * dz;
-                        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(tq.w);
-                        best = (key < best) ? key : best;
+                    for (int sgm = 0; sgm < 2; ++sgm) {
+                        const int s0 = max(seg_lo[sgm], xlo), s1 = min(seg_hi[sgm], xhi);
+                        if (s0 > s1) continue;
+                        if (!(occw & occ_range(s0, s1))) continue;
+                        const unsigned int e = starts[rowbase + s1 + 1];
+                        for (unsigned int k = starts[rowbase + s0]; k < e; ++k) {
+                            const float4 tq = sorted[k];
+                            const float dx = x - tq.x, dy = y - tq.y, dz = z - tq.z;
+                            const float d = (dx * dx + dy * dy) + dz * dz;
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(tq.w);
+                            best = (key < best) ? key : best;
+                        }
                     }
                 }
             }
