@@ -121,9 +121,6 @@ static inline int64_t grid_cells_cap(int64_t n2) { const int64_t g = grid_max_fo
 #define GRID_RMAX 3      // shells of the one-query-per-lane pass; whatever it cannot bound goes to the wave-per-query pass
                          // (2: 130 + 158 us, 3: 180 + 52 us, 4: 282 + 45 us on the 256^3 grid)
 #define SCAN_BLOCK 1024
-#define OCC_B 4                                                 // block edge in cells
-#define OCC_N (GRID_MAX_BIG / OCC_B)                          // blocks per axis at most (64: one 64-bit word per (z-block, y-block))
-#define OCC_WORDS (OCC_N * OCC_N)
 
 struct GridInfo {
     unsigned int bb[6];        // order-preserving keys of min xyz, max xyz
@@ -313,37 +310,6 @@ __global__ __launch_bounds__(KT) void k_scan_apply(const unsigned int* __restric
     }
 }
 
-// Block occupancy: bit bx of occ[(cz / 4) * 64 + (cy / 4)] is set when any of the 4 x 4 x 4 cells of block (bx, cy / 4, cz / 4) holds a point.
-// A map is a set of surfaces: the ball around a query that lies off the surface is mostly empty space, but every cell ROW through it
-// still costs two dependent `starts` loads to find that out (a row-level occupancy bit does not help: in a room every row along x ends in
-// a wall -- measured, neutral).  With the block mask a (row, x-range) pair that cannot hold a point is skipped by one cached 8-byte
-// load shared by 16 rows.  One wave per word: lane = x-block, 16 rows x 2 loads each.
-__global__ __launch_bounds__(256) void k_grid_occupancy(const GridInfo* __restrict__ gi, const unsigned int* __restrict__ starts, unsigned long long* __restrict__ occ) {
-    const int d0 = gi->dims[0], d1 = gi->dims[1], d2 = gi->dims[2];
-    const int word = blockIdx.x * 4 + (threadIdx.x >> 6), bx = threadIdx.x & 63;
-    if (word >= OCC_WORDS) return;
-    const int bz = word / OCC_N, by = word - bz * OCC_N;
-    bool any = false;
-    const int x0 = bx * OCC_B, x1 = min(x0 + OCC_B, d0);
-    if (x0 < d0)
-        for (int dz = 0; dz < OCC_B; ++dz)
-            for (int dy = 0; dy < OCC_B; ++dy) {
-                const int cz = bz * OCC_B + dz, cy = by * OCC_B + dy;
-                if (cz < d2 && cy < d1) {
-                    const unsigned int row = (unsigned int)((cz * d1 + cy) * d0);
-                    any |= starts[row + x1] != starts[row + x0];
-                }
-            }
-    const unsigned long long m = __ballot(any);
-    if (bx == 0) occ[word] = m;
-}
-
-// mask of the x-blocks that cells s0 .. s1 (inclusive, s0 <= s1) touch
-__device__ __forceinline__ unsigned long long occ_range(int s0, int s1) {
-    const int b0 = s0 / OCC_B, b1 = s1 / OCC_B;
-    return (b1 - b0 >= 63 ? ~0ull : ((1ull << (b1 - b0 + 1)) - 1ull)) << b0;
-}
-
 __global__ __launch_bounds__(KT) void k_grid_scatter(const float* __restrict__ p, int64_t n, const long long* __restrict__ nptr, const unsigned int* __restrict__ cell_of,
                                                      const unsigned int* __restrict__ starts, unsigned int* __restrict__ fill,
                                                      float4* __restrict__ sorted) {
@@ -367,8 +333,7 @@ __global__ __launch_bounds__(KT) void k_grid_scatter(const float* __restrict__ p
 __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1, int64_t n1, int row_len, GridInfo* __restrict__ gi,
                                                    const unsigned int* __restrict__ starts, const float4* __restrict__ sorted,
                                                    float* __restrict__ dists, long long* idx,
-                                                   unsigned int* __restrict__ unresolved, const float* __restrict__ ref, const long long* warm,
-                                                   const unsigned long long* __restrict__ occ) {
+                                                   unsigned int* __restrict__ unresolved, const float* __restrict__ ref, const long long* warm) {
     int64_t i0 = (int64_t)blockIdx.x * KT + threadIdx.x;
     if (row_len > 0) {
         const int64_t tile = i0 >> 6;
@@ -432,7 +397,6 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
                 for (int sgm = 0; sgm < 2; ++sgm) {
                     const int s0 = max(seg_lo[sgm], xlo), s1 = min(seg_hi[sgm], xhi);
                     if (s0 > s1) continue;
-                    if (!(occ[(cz / OCC_B) * OCC_N + (cy / OCC_B)] & occ_range(s0, s1))) continue;      // no point in any block the range touches
                     unsigned int k = starts[rowbase + s0];
                     const unsigned int e = starts[rowbase + s1 + 1];
                     for (; k + 4 <= e; k += 4) {
@@ -493,8 +457,7 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
 // case every point of the grid is visited once -- the brute force this replaces read all n2 points per query.
 __global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, const GridInfo* __restrict__ gi,
                                                   const unsigned int* __restrict__ starts, const float4* __restrict__ sorted,
-                                                  const unsigned int* __restrict__ unresolved, float* dists, long long* idx,
-                                                  const unsigned long long* __restrict__ occ) {
+                                                  const unsigned int* __restrict__ unresolved, float* dists, long long* idx) {
     const unsigned int cnt = gi->n_unresolved;
     const int lane = threadIdx.x & 63;
     const unsigned int wave0 = blockIdx.x * (KT / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (KT / 64);
@@ -520,60 +483,36 @@ __global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, 
             int lo[3], hi[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) { lo[c] = max(cq[c] - r, 0); hi[c] = min(cq[c] + r, dims[c] - 1); }
+            const int ny = hi[1] - lo[1] + 1, nrows = ny * (hi[2] - lo[2] + 1);
             const float bd0 = __uint_as_float((unsigned int)(best >> 32));   // wave-uniform bound from the previous shells
-            // The lanes take 4 x 4 (z, y) BLOCKS of cell rows, not rows: a block whose box lies outside the ball, or whose occupancy word has no
-            // bit inside the ball's x-extent, is dismissed with one cached 8-byte load -- a far query (radius r cells) then iterates ~r^2 / 16
-            // block tests instead of ~r^2 row tests before it reaches the few rows that hold points.  The bounds are those of the rows, taken for
-            // the block's box (a row's box lies inside it: its distance is not smaller), so nothing a row test would keep is dropped.
-            const int bzlo = lo[2] / OCC_B, bylo = lo[1] / OCC_B, nby = hi[1] / OCC_B - bylo + 1, nblk = nby * (hi[2] / OCC_B - bzlo + 1);
-            for (int tb = lane; tb < nblk; tb += 64) {
-                const int bz = bzlo + tb / nby, by = bylo + tb % nby;
-                const int cz0 = max(bz * OCC_B, lo[2]), cz1 = min(bz * OCC_B + OCC_B - 1, hi[2]);
-                const int cy0 = max(by * OCC_B, lo[1]), cy1 = min(by * OCC_B + OCC_B - 1, hi[1]);
-                int bxlo = lo[0], bxhi = hi[0];
-                if (best != 0xFFFFFFFFFFFFFFFFull) {
-                    const float gzb = fmaxf(fmaxf(org[2] + (float)cz0 * h - z, z - (org[2] + (float)(cz1 + 1) * h)), 0.f);
-                    const float gyb = fmaxf(fmaxf(org[1] + (float)cy0 * h - y, y - (org[1] + (float)(cy1 + 1) * h)), 0.f);
-                    const float gzbs = fmaxf(gzb * 0.999f - eps, 0.f), gybs = fmaxf(gyb * 0.999f - eps, 0.f);
-                    const float dyzb = gzbs * gzbs + gybs * gybs;
-                    if (dyzb > bd0) continue;
-                    const float rxb = sqrtf(bd0 - dyzb) * 1.001f + 2.f * eps;
-                    bxlo = max(bxlo, (int)floorf(fmaxf((x - rxb - org[0]) * ih, -1.f)));
-                    bxhi = min(bxhi, (int)floorf(fminf((x + rxb - org[0]) * ih, 1.0e6f)));
+            for (int t = lane; t < nrows; t += 64) {
+                const int cz = lo[2] + t / ny, cy = lo[1] + t % ny;
+                const bool row_in_prev = cz >= pl[2] && cz <= ph[2] && cy >= pl[1] && cy <= ph[1];
+                const unsigned int rowbase = (unsigned int)((cz * dims[1] + cy) * dims[0]);
+                int seg_lo[2] = {lo[0], 0}, seg_hi[2] = {hi[0], -1};
+                if (row_in_prev) { seg_hi[0] = pl[0] - 1; seg_lo[1] = ph[0] + 1; seg_hi[1] = hi[0]; }
+                int xlo = lo[0], xhi = hi[0];
+                if (best != 0xFFFFFFFFFFFFFFFFull) {           // same exact ball pruning as the per-lane pass
+                    const float gz = fmaxf(fmaxf(org[2] + (float)cz * h - z, z - (org[2] + (float)(cz + 1) * h)), 0.f);
+                    const float gy = fmaxf(fmaxf(org[1] + (float)cy * h - y, y - (org[1] + (float)(cy + 1) * h)), 0.f);
+                    const float gzs = fmaxf(gz * 0.999f - eps, 0.f), gys = fmaxf(gy * 0.999f - eps, 0.f);
+                    const float dyz = gzs * gzs + gys * gys;
+                    if (dyz > bd0) continue;
+                    const float rx = sqrtf(bd0 - dyz) * 1.001f + 2.f * eps;
+                    xlo = max(xlo, (int)floorf(fmaxf((x - rx - org[0]) * ih, -1.f)));
+                    xhi = min(xhi, (int)floorf(fminf((x + rx - org[0]) * ih, 1.0e6f)));
                 }
-                if (bxlo > bxhi) continue;
-                const unsigned long long occw = occ[bz * OCC_N + by];
-                if (!(occw & occ_range(bxlo, bxhi))) continue;
-                for (int cz = cz0; cz <= cz1; ++cz)
-                for (int cy = cy0; cy <= cy1; ++cy) {
-                    const bool row_in_prev = cz >= pl[2] && cz <= ph[2] && cy >= pl[1] && cy <= ph[1];
-                    const unsigned int rowbase = (unsigned int)((cz * dims[1] + cy) * dims[0]);
-                    int seg_lo[2] = {lo[0], 0}, seg_hi[2] = {hi[0], -1};
-                    if (row_in_prev) { seg_hi[0] = pl[0] - 1; seg_lo[1] = ph[0] + 1; seg_hi[1] = hi[0]; }
-                    int xlo = lo[0], xhi = hi[0];
-                    if (best != 0xFFFFFFFFFFFFFFFFull) {           // same exact ball pruning as the per-lane pass
-                        const float gz = fmaxf(fmaxf(org[2] + (float)cz * h - z, z - (org[2] + (float)(cz + 1) * h)), 0.f);
-                        const float gy = fmaxf(fmaxf(org[1] + (float)cy * h - y, y - (org[1] + (float)(cy + 1) * h)), 0.f);
-                        const float gzs = fmaxf(gz * 0.999f - eps, 0.f), gys = fmaxf(gy * 0.999f - eps, 0.f);
-                        const float dyz = gzs * gzs + gys * gys;
-                        if (dyz > bd0) continue;
-                        const float rx = sqrtf(bd0 - dyz) * 1.001f + 2.f * eps;
-                        xlo = max(xlo, (int)floorf(fmaxf((x - rx - org[0]) * ih, -1.f)));
-                        xhi = min(xhi, (int)floorf(fminf((x + rx - org[0]) * ih, 1.0e6f)));
-                    }
 #pragma unroll
-                    for (int sgm = 0; sgm < 2; ++sgm) {
-                        const int s0 = max(seg_lo[sgm], xlo), s1 = min(seg_hi[sgm], xhi);
-                        if (s0 > s1) continue;
-                        if (!(occw & occ_range(s0, s1))) continue;
-                        const unsigned int e = starts[rowbase + s1 + 1];
-                        for (unsigned int k = starts[rowbase + s0]; k < e; ++k) {
-                            const float4 tq = sorted[k];
-                            const float dx = x - tq.x, dy = y - tq.y, dz = z - tq.z;
-                            const float d = (dx * dx + dy * dy) + dz * dz;
-                            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(tq.w);
-                            best = (key < best) ? key : best;
-                        }
+                for (int sgm = 0; sgm < 2; ++sgm) {
+                    const int s0 = max(seg_lo[sgm], xlo), s1 = min(seg_hi[sgm], xhi);
+                    if (s0 > s1) continue;
+                    const unsigned int e = starts[rowbase + s1 + 1];
+                    for (unsigned int k = starts[rowbase + s0]; k < e; ++k) {
+                        const float4 tq = sorted[k];
+                        const float dx = x - tq.x, dy = y - tq.y, dz = z - tq.z;
+                        const float d = (dx * dx + dy * dy) + dz * dz;
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(tq.w);
+                        best = (key < best) ? key : best;
                     }
                 }
             }
@@ -640,7 +579,7 @@ static int64_t grid_ws_bytes(int64_t n1, int64_t n2, bool big_always = false, in
     const int64_t nc = cells > 0 ? (int64_t)cells * cells * cells : (big_always ? (int64_t)GRID_MAX_BIG * GRID_MAX_BIG * GRID_MAX_BIG : grid_cells_cap(n2)),
                   nb = (nc + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
     // GridInfo | counts[nc+1] | starts[nc+1] | fill[nc] | bsum[nb] | cell_of[n2] | unresolved[n1] | sorted float4[n2]
-    return 256 + 4 * (nc + 1) * 2 + 4 * nc + 4 * (nb + 1) + 4 * 6 * BBOX_BLOCKS + 8 + 8 * OCC_WORDS + 4 * n2 + 4 * n1 + 64 + 16 * n2;
+    return 256 + 4 * (nc + 1) * 2 + 4 * nc + 4 * (nb + 1) + 4 * 6 * BBOX_BLOCKS + 4 * n2 + 4 * n1 + 64 + 16 * n2;
 }
 
 int64_t e2e_knn1_workspace_bytes(int64_t n1, int64_t n2) {
@@ -653,7 +592,6 @@ int64_t e2e_knn1_workspace_bytes(int64_t n1, int64_t n2) {
 struct GridWs {
     GridInfo* gi;
     unsigned int *counts, *starts, *fill, *bsum, *bbpart, *cell_of, *unresolved;
-    unsigned long long* occ;
     float4* sorted;
     int64_t nc;
     int nb;
@@ -672,8 +610,6 @@ static GridWs grid_ws(void* workspace, int64_t nq, int64_t n2, bool big_always =
     g.fill = (unsigned int*)w; w += 4 * g.nc;
     g.bsum = (unsigned int*)w; w += 4 * (g.nb + 1);
     g.bbpart = (unsigned int*)w; w += 4 * 6 * BBOX_BLOCKS;
-    w = (char*)(((uintptr_t)w + 7) & ~(uintptr_t)7);
-    g.occ = (unsigned long long*)w; w += 8 * OCC_WORDS;
     g.cell_of = (unsigned int*)w; w += 4 * n2;
     g.unresolved = (unsigned int*)w; w += 4 * nq;
     w = (char*)(((uintptr_t)w + 63) & ~(uintptr_t)63);
@@ -695,7 +631,6 @@ static void grid_build(const float* p2, int64_t n2, const long long* n2_dev, con
     hipLaunchKernelGGL(k_scan_blocksum, dim3(g.nb), dim3(KT), 0, st, g.counts, nscan, g.bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, g.bsum, g.nb);
     hipLaunchKernelGGL(k_scan_apply, dim3(g.nb), dim3(KT), 0, st, g.counts, nscan, g.bsum, g.starts);
-    hipLaunchKernelGGL(k_grid_occupancy, dim3(OCC_WORDS / 4), dim3(256), 0, st, g.gi, g.starts, g.occ);
     hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(KT), 0, st, p2, n2, n2_dev, g.cell_of, g.starts, g.fill, g.sorted);
 }
 
@@ -704,13 +639,13 @@ static void grid_query(const float* p1, int64_t n1, const GridWs& g, float* dist
     if (row_len <= 0 || (row_len & 7) || n1 % ((int64_t)row_len * 8)) row_len = 0;      // tile order needs whole 8 x 8 tiles
     if (!ref) warm = nullptr;
     hipLaunchKernelGGL(k_grid_query, dim3((unsigned)((n1 + KT - 1) / KT)), dim3(KT), 0, st, p1, n1, row_len, g.gi, g.starts, g.sorted, dists, idx, g.unresolved, ref,
-                       warm, g.occ);
+                       warm);
     // one WAVE per unresolved query: 1024 workgroups (4096 waves) suit the refinement queries, of which a few per cent stay unresolved; a small
     // query set that is mostly unresolved (frame-to-model odometry while the pose is still wrong: 19 200 queries, decimetres off the targets)
     // gets a wave per query instead of 2-5 queries per wave in sequence -- idle workgroups leave at once
     const int64_t rest_blocks = n1 <= 65536 ? (n1 + 3) / 4 : 1024;
     hipLaunchKernelGGL(k_knn1_rest, dim3((unsigned)(rest_blocks < 1024 ? 1024 : (rest_blocks > 8192 ? 8192 : rest_blocks))), dim3(KT), 0, st, p1, g.gi, g.starts,
-                       g.sorted, g.unresolved, dists, idx, g.occ);
+                       g.sorted, g.unresolved, dists, idx);
 }
 
 static int knn1_grid(const float* p1, int64_t n1, const float* p2, int64_t n2, float* dists, long long* idx, void* workspace, hipStream_t st) {
@@ -806,7 +741,7 @@ int e2e_knn1_index_query_dev_res(const float* p1, int64_t n1, const float* ref_p
     hipStream_t st = (hipStream_t)stream;
     if (n1 <= 32768) {                                          // a wave per query from the start (see k_knn1_all_unresolved)
         hipLaunchKernelGGL(k_knn1_all_unresolved, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, p1, n1, g.gi, g.unresolved, ref_points, warm_idx, dists, idx);
-        hipLaunchKernelGGL(k_knn1_rest, dim3((unsigned)((n1 + 3) / 4)), dim3(KT), 0, st, p1, g.gi, g.starts, g.sorted, g.unresolved, dists, idx, g.occ);
+        hipLaunchKernelGGL(k_knn1_rest, dim3((unsigned)((n1 + 3) / 4)), dim3(KT), 0, st, p1, g.gi, g.starts, g.sorted, g.unresolved, dists, idx);
     } else {
         hipLaunchKernelGGL(k_grid_reset_unresolved, dim3(1), dim3(1), 0, st, g.gi);
         grid_query(p1, n1, g, dists, idx, st, 0, ref_points, warm_idx);
