@@ -128,6 +128,7 @@ struct GridInfo {
     int dims[3];
     unsigned int n_unresolved;
     unsigned int n_points;     // reference points the index was built over (validates warm-start indices)
+    unsigned int n_cells;      // dims[0] * dims[1] * dims[2]: the cells the build addresses (the workspace holds the cubic budget)
     float eps;                 // absolute slack of every geometric bound: fp32 rounding of (v - origin) * inv_h at the cloud's
 };                             // largest coordinate can move a point across a cell face by a few ulps of that coordinate
 
@@ -137,28 +138,40 @@ __device__ __forceinline__ unsigned int fkey(float f) {
 }
 __device__ __forceinline__ float fkey_inv(unsigned int k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 
-__global__ void k_grid_init(GridInfo* gi, unsigned int* counts, unsigned int* fill, int64_t ncell) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= ncell; i += (int64_t)gridDim.x * blockDim.x) {
-        counts[i] = 0;
-        if (i < ncell) fill[i] = 0;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        gi->bb[0] = gi->bb[1] = gi->bb[2] = 0xFFFFFFFFu;
-        gi->bb[3] = gi->bb[4] = gi->bb[5] = 0u;
-        gi->n_unresolved = 0;
+// counters of the cells the box at hand addresses (+ the scan's end slot): a map's box is rarely a cube, so this is typically half of the budget
+__global__ void k_grid_zero(const GridInfo* __restrict__ gi, unsigned int* __restrict__ counts) {
+    const int64_t n = (int64_t)gi->n_cells + 1;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= n) *(uint4*)(counts + i) = make_uint4(0u, 0u, 0u, 0u);
+        else for (int64_t j = i; j < n; ++j) counts[j] = 0u;
     }
 }
 
 // NOTE: device-scope atomics that hit ONE address serialise at the memory side at ~0.18 us each (3072 of them made
 // this kernel 555 us): the workgroups publish their partial boxes instead and k_grid_setup folds them.
-#define BBOX_BLOCKS 256
+#define BBOX_BLOCKS 256          // threads of k_grid_setup
+#define BBOX_MAX_PARTS 2048      // workgroups of k_grid_bbox = partial boxes k_grid_setup folds
 // `nptr` (every build kernel): when not NULL the number of reference points is read from DEVICE memory (a resident map whose size the
 // host never learns: e2e_knn1_index_build_dev); grids are then sized by the capacity and the loops stop at *nptr
-__global__ __launch_bounds__(KT) void k_grid_bbox(const float* __restrict__ p, int64_t n, const long long* __restrict__ nptr, unsigned int* __restrict__ part) {
+// vec != 0 (p is 16-byte aligned): a lane reads FOUR points as three float4s of the flat coordinate stream -- 48 contiguous bytes, three loads in
+// flight -- instead of twelve dwords at stride 12 (the scalar loop left this kernel latency-bound at 1.6 TB/s on an 11 M point map)
+__global__ __launch_bounds__(KT) void k_grid_bbox(const float* __restrict__ p, int64_t n, const long long* __restrict__ nptr, unsigned int* __restrict__ part, int vec) {
     __shared__ unsigned int slo[3][KT / 64], shi[3][KT / 64];
     if (nptr) n = (int64_t)*nptr;
     unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
-    for (int64_t i = (int64_t)blockIdx.x * KT + threadIdx.x; i < n; i += (int64_t)gridDim.x * KT)
+    const int64_t n4 = vec ? n / 4 : 0;
+    for (int64_t g = (int64_t)blockIdx.x * KT + threadIdx.x; g < n4; g += (int64_t)gridDim.x * KT) {
+        const float4* q = (const float4*)(p + g * 12);
+        const float4 a = q[0], b = q[1], d = q[2];
+        const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const unsigned int k = fkey(v[j]);
+            lo[j % 3] = min(lo[j % 3], k);
+            hi[j % 3] = max(hi[j % 3], k);
+        }
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * KT + threadIdx.x; i < n; i += (int64_t)gridDim.x * KT)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const unsigned int k = fkey(p[i * 3 + c]);
@@ -189,9 +202,10 @@ __global__ __launch_bounds__(BBOX_BLOCKS) void k_grid_setup(GridInfo* gi, const 
     __shared__ unsigned int sh[6][BBOX_BLOCKS / 64];
     if (nptr) gmax = (*nptr >= GRID_BIG_N2) ? GRID_MAX_BIG : GRID_MAX_SMALL;      // the host's rule (grid_max_for) on the device-resident count
     if (gmax_force > 0) gmax = gmax_force;
-    if (threadIdx.x == 0) gi->n_points = (unsigned int)(nptr ? *nptr : n_host);
+    if (threadIdx.x == 0) { gi->n_points = (unsigned int)(nptr ? *nptr : n_host); gi->n_unresolved = 0; }
     for (int c = 0; c < 6; ++c) {
-        unsigned int v = (threadIdx.x < nparts) ? part[threadIdx.x * 6 + c] : (c < 3 ? 0xFFFFFFFFu : 0u);
+        unsigned int v = c < 3 ? 0xFFFFFFFFu : 0u;
+        for (int j = threadIdx.x; j < nparts; j += BBOX_BLOCKS) v = (c < 3) ? min(v, part[j * 6 + c]) : max(v, part[j * 6 + c]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned int w = (unsigned int)__shfl_down((int)v, o, 64);
@@ -216,7 +230,9 @@ __global__ __launch_bounds__(BBOX_BLOCKS) void k_grid_setup(GridInfo* gi, const 
     // budget), up to 1024 cells along an axis).  Exact all the same, but SLOWER on the refinement path: the queries are back-projected
     // PREDICTED depths, typically several cells away from the map surface, and the shell search visits ~(1/h)^3 cells to cover that
     // distance -- 0.71 -> 1.12 ms per keyframe at 1.66 M points, 177.3 -> 172.0 steps/s over a whole pass
-    // (profiles/r03_knn_adaptive_cells_rejected.txt).  Reverted.
+    // (profiles/r03_knn_adaptive_cells_rejected.txt).  Reverted.  Round 4 tried the milder rule "refine only once the box holds more than
+    // ppc points per cell on average" (the map ends a pass of the benchmark sequence at 9.9 per cell): ppc 1.5 / 2.5 / 4 / 6 gave 194.6 /
+    // 196.5 / 197.1 / 197.2 steps/s over a whole pass against 197.1 without it (profiles/r04_knn_density_cells_rejected.txt).  Not kept.
     const float h = fmaxf(ext / (float)(gmax - 1), GRID_HMIN);
     float maxabs = 0.f;
     for (int c = 0; c < 3; ++c) maxabs = fmaxf(maxabs, fmaxf(fabsf(lo[c]), fabsf(fkey_inv(gi->bb[3 + c]))));
@@ -228,29 +244,63 @@ __global__ __launch_bounds__(BBOX_BLOCKS) void k_grid_setup(GridInfo* gi, const 
         int d = (int)floorf((fkey_inv(gi->bb[3 + c]) - lo[c]) / h) + 1;
         gi->dims[c] = min(max(d, 1), gmax);
     }
+    gi->n_cells = (unsigned int)(gi->dims[0] * gi->dims[1] * gi->dims[2]);
 }
 
 __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int dim) {
     return min(max((int)floorf((v - o) * inv_h), 0), dim - 1);
 }
 
-__global__ __launch_bounds__(KT) void k_grid_count(const float* __restrict__ p, int64_t n, const long long* __restrict__ nptr, const GridInfo* __restrict__ gi,
-                                                   unsigned int* __restrict__ cell_of, unsigned int* __restrict__ counts) {
-    if (nptr) n = (int64_t)*nptr;
-    const float ox = gi->origin[0], oy = gi->origin[1], oz = gi->origin[2], ih = gi->inv_h;
-    const int dx = gi->dims[0], dy = gi->dims[1], dz = gi->dims[2];
-    for (int64_t i = (int64_t)blockIdx.x * KT + threadIdx.x; i < n; i += (int64_t)gridDim.x * KT) {
-        const int cx = cell_coord(p[i * 3], ox, ih, dx), cy = cell_coord(p[i * 3 + 1], oy, ih, dy), cz = cell_coord(p[i * 3 + 2], oz, ih, dz);
-        const unsigned int c = (unsigned int)((cz * dy + cy) * dx + cx);
-        cell_of[i] = c;
-        atomicAdd(&counts[c], 1u);
+// Lanes of a wave that fall into the same cell share ONE atomic: the map is stored in frame order, so the 64 consecutive points of a wave are
+// neighbouring pixels of one frame and land in a handful of cells.  One round per distinct cell (ballot on the first ungrouped lane's cell): at
+// worst 64 rounds of a dozen scalar / lane instructions, which is nothing next to a device-scope atomic -- on this part those execute at the
+// memory side, not in the XCD's L2, and their rate bounds both kernels.  group_by_cell returns, per lane, the leader lane of its group, its rank
+// in the group and the group's size.
+__device__ __forceinline__ void group_by_cell(unsigned int c, bool act, int lane, int& leader_of, unsigned int& rank, unsigned int& gsize) {
+    leader_of = lane; rank = 0u; gsize = 1u;
+    unsigned long long rem = __ballot(act);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    while (rem) {
+        const int leader = (int)__builtin_ctzll(rem);
+        const unsigned int cl = (unsigned int)__builtin_amdgcn_readlane((int)c, leader);
+        const unsigned long long m = __ballot(act && c == cl) & rem;
+        if ((m >> lane) & 1ull) {
+            leader_of = leader;
+            rank = (unsigned int)__builtin_popcountll(m & below);
+            gsize = (unsigned int)__builtin_popcountll(m);
+        }
+        rem &= ~m;
     }
 }
 
-// three-kernel exclusive scan over ncell+1 counters: block sums -> scan of block sums -> local scan + offset
-__global__ __launch_bounds__(KT) void k_scan_blocksum(const unsigned int* __restrict__ v, int64_t n, unsigned int* __restrict__ bsum) {
+__global__ __launch_bounds__(KT) void k_grid_count(const float* __restrict__ p, int64_t n, const long long* __restrict__ nptr, const GridInfo* __restrict__ gi,
+                                                   unsigned int* __restrict__ counts) {
+    if (nptr) n = (int64_t)*nptr;
+    const float ox = gi->origin[0], oy = gi->origin[1], oz = gi->origin[2], ih = gi->inv_h;
+    const int dx = gi->dims[0], dy = gi->dims[1], dz = gi->dims[2];
+    const int lane = threadIdx.x & 63;
+    for (int64_t b = (int64_t)blockIdx.x * KT + (threadIdx.x & ~63); b < n; b += (int64_t)gridDim.x * KT) {      // wave-uniform trip count
+        const int64_t i = b + lane;
+        const bool act = i < n;
+        unsigned int c = 0xFFFFFFFFu;
+        if (act) {
+            const int cx = cell_coord(p[i * 3], ox, ih, dx), cy = cell_coord(p[i * 3 + 1], oy, ih, dy), cz = cell_coord(p[i * 3 + 2], oz, ih, dz);
+            c = (unsigned int)((cz * dy + cy) * dx + cx);
+        }
+        int leader_of;
+        unsigned int rank, gsize;
+        group_by_cell(c, act, lane, leader_of, rank, gsize);
+        if (act && leader_of == lane) atomicAdd(&counts[c], gsize);
+    }
+}
+
+// three-kernel exclusive scan over the n_cells + 1 counters the box addresses (launched for the cubic budget; workgroups beyond leave at once):
+// block sums -> scan of block sums -> local scan + offset
+__global__ __launch_bounds__(KT) void k_scan_blocksum(const unsigned int* __restrict__ v, const GridInfo* __restrict__ gi, unsigned int* __restrict__ bsum) {
     __shared__ unsigned int sh[KT / 64];
+    const int64_t n = (int64_t)gi->n_cells + 1;
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+    if ((int64_t)blockIdx.x * SCAN_BLOCK >= n) return;
     unsigned int s = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) s += (base + j < n) ? v[base + j] : 0u;
@@ -260,9 +310,10 @@ __global__ __launch_bounds__(KT) void k_scan_blocksum(const unsigned int* __rest
     __syncthreads();
     if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
-__global__ __launch_bounds__(1024) void k_scan_bsums(unsigned int* __restrict__ bsum, int nb) {
+__global__ __launch_bounds__(1024) void k_scan_bsums(unsigned int* __restrict__ bsum, const GridInfo* __restrict__ gi) {
     __shared__ unsigned int wsum[16];
     __shared__ unsigned int carry_s;
+    const int nb = (int)(((int64_t)gi->n_cells + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK);
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     for (int base = 0; base < nb; base += 1024) {
@@ -285,9 +336,11 @@ __global__ __launch_bounds__(1024) void k_scan_bsums(unsigned int* __restrict__ 
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(KT) void k_scan_apply(const unsigned int* __restrict__ v, int64_t n, const unsigned int* __restrict__ bsum,
+__global__ __launch_bounds__(KT) void k_scan_apply(const unsigned int* __restrict__ v, const GridInfo* __restrict__ gi, const unsigned int* __restrict__ bsum,
                                                    unsigned int* __restrict__ out) {
     __shared__ unsigned int sh[KT / 64];
+    const int64_t n = (int64_t)gi->n_cells + 1;
+    if ((int64_t)blockIdx.x * SCAN_BLOCK >= n) return;
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
     unsigned int a[4], s = 0;
 #pragma unroll
@@ -310,14 +363,33 @@ __global__ __launch_bounds__(KT) void k_scan_apply(const unsigned int* __restric
     }
 }
 
-__global__ __launch_bounds__(KT) void k_grid_scatter(const float* __restrict__ p, int64_t n, const long long* __restrict__ nptr, const unsigned int* __restrict__ cell_of,
-                                                     const unsigned int* __restrict__ starts, unsigned int* __restrict__ fill,
+// counting-sort scatter.  The per-cell counters double as cursors (they are not needed once scanned): a group of `gsize` same-cell lanes takes the
+// slots [old - gsize, old) of its cell with one atomicSub, so the lanes of a group write CONSECUTIVE float4s.  The cell is recomputed from the point
+// (the same expression on the same inputs as k_grid_count) instead of being carried through memory.
+__global__ __launch_bounds__(KT) void k_grid_scatter(const float* __restrict__ p, int64_t n, const long long* __restrict__ nptr, const GridInfo* __restrict__ gi,
+                                                     const unsigned int* __restrict__ starts, unsigned int* __restrict__ counts,
                                                      float4* __restrict__ sorted) {
     if (nptr) n = (int64_t)*nptr;
-    for (int64_t i = (int64_t)blockIdx.x * KT + threadIdx.x; i < n; i += (int64_t)gridDim.x * KT) {
-        const unsigned int c = cell_of[i];
-        const unsigned int pos = starts[c] + atomicAdd(&fill[c], 1u);
-        sorted[pos] = make_float4(p[i * 3], p[i * 3 + 1], p[i * 3 + 2], __uint_as_float((unsigned int)i));
+    const float ox = gi->origin[0], oy = gi->origin[1], oz = gi->origin[2], ih = gi->inv_h;
+    const int dx = gi->dims[0], dy = gi->dims[1], dz = gi->dims[2];
+    const int lane = threadIdx.x & 63;
+    for (int64_t b = (int64_t)blockIdx.x * KT + (threadIdx.x & ~63); b < n; b += (int64_t)gridDim.x * KT) {
+        const int64_t i = b + lane;
+        const bool act = i < n;
+        unsigned int c = 0xFFFFFFFFu;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (act) {
+            x = p[i * 3]; y = p[i * 3 + 1]; z = p[i * 3 + 2];
+            const int cx = cell_coord(x, ox, ih, dx), cy = cell_coord(y, oy, ih, dy), cz = cell_coord(z, oz, ih, dz);
+            c = (unsigned int)((cz * dy + cy) * dx + cx);
+        }
+        int leader_of;
+        unsigned int rank, gsize;
+        group_by_cell(c, act, lane, leader_of, rank, gsize);
+        unsigned int old = 0u;
+        if (act && leader_of == lane) old = atomicSub(&counts[c], gsize);
+        old = (unsigned int)__shfl((int)old, leader_of, 64);
+        if (act) sorted[starts[c] + old - gsize + rank] = make_float4(x, y, z, __uint_as_float((unsigned int)i));
     }
 }
 
@@ -452,9 +524,19 @@ __global__ __launch_bounds__(KT) void k_grid_query(const float* __restrict__ p1,
 }
 
 // Queries the per-lane pass could not bound within GRID_RMAX shells (they look at a part of the scene the map does not
-// cover yet) are finished by ONE WAVE each: same shell search, the (cz,cy) rows of every shell spread over the 64
-// lanes, (distance, index) keys combined with integer min.  While nothing has been found the radius doubles.  Worst
-// case every point of the grid is visited once -- the brute force this replaces read all n2 points per query.
+// cover yet) are finished by ONE WAVE each: same shell search, (distance, index) keys combined with integer min.  While
+// nothing has been found the radius doubles.  Worst case every point of the grid is visited once -- the brute force this
+// replaces read all n2 points per query.
+// Work distribution inside the wave: the (cz,cy) rows of a shell go to the lanes 64 at a time, each lane works out the
+// range(s) of `sorted` its row contributes (two dependent loads of `starts`), and then the POINTS of all 64 ranges -- not the
+// rows -- are dealt to the lanes: an inclusive scan of the range lengths over the wave, and lane l takes the points l, l + 64, ...
+// of the concatenation (a 6-step binary search over the scan, by lane permutes, finds the range a point belongs to).  Rows
+// crossing the map surface hold hundreds of points next to rows holding none; a lane per row left one lane scanning such a row
+// point by point with the others idle, which made this pass grow from 38 to 423 us over a pass of the benchmark sequence
+// (0.7 -> 11.7 M map points).  Consecutive lanes now read consecutive float4s, and 64 points are in flight per step.
+// What is left is latency: a far query (a pixel looking at a part of the scene the map does not cover: nearest point a metre = 30 cells
+// away) walks thousands of rows, two dependent loads each, so a lane takes REST_ROWS rows per batch with all their `starts` words in flight.
+#define REST_ROWS 4
 __global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, const GridInfo* __restrict__ gi,
                                                   const unsigned int* __restrict__ starts, const float4* __restrict__ sorted,
                                                   const unsigned int* __restrict__ unresolved, float* dists, long long* idx) {
@@ -484,35 +566,86 @@ __global__ __launch_bounds__(KT) void k_knn1_rest(const float* __restrict__ p1, 
 #pragma unroll
             for (int c = 0; c < 3; ++c) { lo[c] = max(cq[c] - r, 0); hi[c] = min(cq[c] + r, dims[c] - 1); }
             const int ny = hi[1] - lo[1] + 1, nrows = ny * (hi[2] - lo[2] + 1);
-            const float bd0 = __uint_as_float((unsigned int)(best >> 32));   // wave-uniform bound from the previous shells
-            for (int t = lane; t < nrows; t += 64) {
-                const int cz = lo[2] + t / ny, cy = lo[1] + t % ny;
-                const bool row_in_prev = cz >= pl[2] && cz <= ph[2] && cy >= pl[1] && cy <= ph[1];
-                const unsigned int rowbase = (unsigned int)((cz * dims[1] + cy) * dims[0]);
-                int seg_lo[2] = {lo[0], 0}, seg_hi[2] = {hi[0], -1};
-                if (row_in_prev) { seg_hi[0] = pl[0] - 1; seg_lo[1] = ph[0] + 1; seg_hi[1] = hi[0]; }
-                int xlo = lo[0], xhi = hi[0];
-                if (best != 0xFFFFFFFFFFFFFFFFull) {           // same exact ball pruning as the per-lane pass
-                    const float gz = fmaxf(fmaxf(org[2] + (float)cz * h - z, z - (org[2] + (float)(cz + 1) * h)), 0.f);
-                    const float gy = fmaxf(fmaxf(org[1] + (float)cy * h - y, y - (org[1] + (float)(cy + 1) * h)), 0.f);
-                    const float gzs = fmaxf(gz * 0.999f - eps, 0.f), gys = fmaxf(gy * 0.999f - eps, 0.f);
-                    const float dyz = gzs * gzs + gys * gys;
-                    if (dyz > bd0) continue;
-                    const float rx = sqrtf(bd0 - dyz) * 1.001f + 2.f * eps;
-                    xlo = max(xlo, (int)floorf(fmaxf((x - rx - org[0]) * ih, -1.f)));
-                    xhi = min(xhi, (int)floorf(fminf((x + rx - org[0]) * ih, 1.0e6f)));
-                }
+            for (int t0 = 0; t0 < nrows; t0 += 64 * REST_ROWS) {             // wave-uniform trip count: all lanes take part in the permutes below
+                // the bound, refreshed per batch of rows: the smallest distance any lane holds (bit patterns of non-negative floats order like
+                // unsigned integers; 0xFFFFFFFF = nothing yet).  A far query then stops reading rows outside the ball of the first points it meets
+                // instead of scanning the whole doubled cube.
+                unsigned int bdu = (unsigned int)(best >> 32);
 #pragma unroll
-                for (int sgm = 0; sgm < 2; ++sgm) {
-                    const int s0 = max(seg_lo[sgm], xlo), s1 = min(seg_hi[sgm], xhi);
-                    if (s0 > s1) continue;
-                    const unsigned int e = starts[rowbase + s1 + 1];
-                    for (unsigned int k = starts[rowbase + s0]; k < e; ++k) {
-                        const float4 tq = sorted[k];
-                        const float dx = x - tq.x, dy = y - tq.y, dz = z - tq.z;
-                        const float d = (dx * dx + dy * dy) + dz * dz;
-                        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(tq.w);
-                        best = (key < best) ? key : best;
+                for (int o = 32; o > 0; o >>= 1) bdu = min(bdu, (unsigned int)__shfl_xor((int)bdu, o, 64));
+                const bool bounded = bdu != 0xFFFFFFFFu;
+                const float bd0 = __uint_as_float(bdu);
+                // REST_ROWS rows per lane and batch, their `starts` words fetched together (a pruned row reads word 0 twice: length 0)
+                unsigned int ia[REST_ROWS][4];
+#pragma unroll
+                for (int j = 0; j < REST_ROWS; ++j) {
+                    const int t = t0 + j * 64 + lane;
+                    ia[j][0] = ia[j][1] = ia[j][2] = ia[j][3] = 0u;
+                    if (t < nrows) {
+                        const int cz = lo[2] + t / ny, cy = lo[1] + t % ny;
+                        const bool row_in_prev = cz >= pl[2] && cz <= ph[2] && cy >= pl[1] && cy <= ph[1];
+                        const unsigned int rowbase = (unsigned int)((cz * dims[1] + cy) * dims[0]);
+                        int seg_lo[2] = {lo[0], 0}, seg_hi[2] = {hi[0], -1};
+                        if (row_in_prev) { seg_hi[0] = pl[0] - 1; seg_lo[1] = ph[0] + 1; seg_hi[1] = hi[0]; }
+                        int xlo = lo[0], xhi = hi[0];
+                        bool keep = true;
+                        if (bounded) {                         // same exact ball pruning as the per-lane pass
+                            const float gz = fmaxf(fmaxf(org[2] + (float)cz * h - z, z - (org[2] + (float)(cz + 1) * h)), 0.f);
+                            const float gy = fmaxf(fmaxf(org[1] + (float)cy * h - y, y - (org[1] + (float)(cy + 1) * h)), 0.f);
+                            const float gzs = fmaxf(gz * 0.999f - eps, 0.f), gys = fmaxf(gy * 0.999f - eps, 0.f);
+                            const float dyz = gzs * gzs + gys * gys;
+                            keep = !(dyz > bd0);
+                            const float rx = sqrtf(fmaxf(bd0 - dyz, 0.f)) * 1.001f + 2.f * eps;
+                            xlo = max(xlo, (int)floorf(fmaxf((x - rx - org[0]) * ih, -1.f)));
+                            xhi = min(xhi, (int)floorf(fminf((x + rx - org[0]) * ih, 1.0e6f)));
+                        }
+                        if (keep) {
+                            const int a0 = max(seg_lo[0], xlo), a1 = min(seg_hi[0], xhi), b0 = max(seg_lo[1], xlo), b1 = min(seg_hi[1], xhi);
+                            if (a0 <= a1) { ia[j][0] = rowbase + a0; ia[j][1] = rowbase + a1 + 1; }
+                            if (b0 <= b1) { ia[j][2] = rowbase + b0; ia[j][3] = rowbase + b1 + 1; }
+                        }
+                    }
+                }
+                unsigned int sv[REST_ROWS][4];
+#pragma unroll
+                for (int j = 0; j < REST_ROWS; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sv[j][e] = starts[ia[j][e]];
+#pragma unroll
+                for (int j = 0; j < REST_ROWS; ++j) {
+                    if (t0 + j * 64 >= nrows) break;                          // wave-uniform
+                    const unsigned int ka = sv[j][0], la = sv[j][1] - sv[j][0], kb = sv[j][2], lb = sv[j][3] - sv[j][2];
+                    const unsigned int len = la + lb;
+                    unsigned int incl = len;                                   // inclusive scan of the lengths over the wave
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const unsigned int v = (unsigned int)__shfl_up((int)incl, o, 64);
+                        if (lane >= o) incl += v;
+                    }
+                    const unsigned int total = (unsigned int)__shfl((int)incl, 63, 64);
+                    for (unsigned int g0 = 0; g0 < total; g0 += 64) {
+                        const unsigned int g = g0 + lane;
+                        const bool live = g < total;
+                        const unsigned int gg = live ? g : total - 1u;
+                        int lo_l = 0, hi_l = 63;                               // first lane whose inclusive sum exceeds gg (exists: gg < total)
+#pragma unroll
+                        for (int sidx = 0; sidx < 6; ++sidx) {
+                            const int mid = (lo_l + hi_l) >> 1;
+                            const unsigned int v = (unsigned int)__shfl((int)incl, mid, 64);
+                            if (v <= gg) lo_l = mid + 1; else hi_l = mid;
+                        }
+                        const unsigned int r_incl = (unsigned int)__shfl((int)incl, lo_l, 64), r_len = (unsigned int)__shfl((int)len, lo_l, 64);
+                        const unsigned int r_ka = (unsigned int)__shfl((int)ka, lo_l, 64), r_la = (unsigned int)__shfl((int)la, lo_l, 64);
+                        const unsigned int r_kb = (unsigned int)__shfl((int)kb, lo_l, 64);
+                        const unsigned int off = gg - (r_incl - r_len);
+                        const unsigned int k = off < r_la ? r_ka + off : r_kb + (off - r_la);
+                        if (live) {
+                            const float4 tq = sorted[k];
+                            const float dx = x - tq.x, dy = y - tq.y, dz = z - tq.z;
+                            const float d = (dx * dx + dy * dy) + dz * dz;
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(tq.w);
+                            best = (key < best) ? key : best;
+                        }
                     }
                 }
             }
@@ -578,8 +711,8 @@ static int knn1_brute(const float* p1, int64_t n1, const float* p2, int64_t n2, 
 static int64_t grid_ws_bytes(int64_t n1, int64_t n2, bool big_always = false, int cells = 0) {
     const int64_t nc = cells > 0 ? (int64_t)cells * cells * cells : (big_always ? (int64_t)GRID_MAX_BIG * GRID_MAX_BIG * GRID_MAX_BIG : grid_cells_cap(n2)),
                   nb = (nc + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    // GridInfo | counts[nc+1] | starts[nc+1] | fill[nc] | bsum[nb] | cell_of[n2] | unresolved[n1] | sorted float4[n2]
-    return 256 + 4 * (nc + 1) * 2 + 4 * nc + 4 * (nb + 1) + 4 * 6 * BBOX_BLOCKS + 4 * n2 + 4 * n1 + 64 + 16 * n2;
+    // GridInfo | counts[nc+1 .. 16 B] | starts[nc+1 .. 16 B] | bsum[nb] | bbpart | unresolved[n1] | sorted float4[n2]
+    return 256 + 4 * (nc + 4) * 2 + 4 * (nb + 1) + 4 * 6 * BBOX_MAX_PARTS + 4 * n1 + 64 + 16 * n2;
 }
 
 int64_t e2e_knn1_workspace_bytes(int64_t n1, int64_t n2) {
@@ -591,7 +724,7 @@ int64_t e2e_knn1_workspace_bytes(int64_t n1, int64_t n2) {
 
 struct GridWs {
     GridInfo* gi;
-    unsigned int *counts, *starts, *fill, *bsum, *bbpart, *cell_of, *unresolved;
+    unsigned int *counts, *starts, *bsum, *bbpart, *unresolved;
     float4* sorted;
     int64_t nc;
     int nb;
@@ -605,12 +738,10 @@ static GridWs grid_ws(void* workspace, int64_t nq, int64_t n2, bool big_always =
     g.nb = (int)((g.nc + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK);
     char* w = (char*)workspace;
     g.gi = (GridInfo*)w; w += 256;
-    g.counts = (unsigned int*)w; w += 4 * (g.nc + 1);
-    g.starts = (unsigned int*)w; w += 4 * (g.nc + 1);
-    g.fill = (unsigned int*)w; w += 4 * g.nc;
+    g.counts = (unsigned int*)w; w += 4 * ((g.nc + 4) & ~(int64_t)3);          // 16-byte aligned (k_grid_zero stores uint4s)
+    g.starts = (unsigned int*)w; w += 4 * ((g.nc + 4) & ~(int64_t)3);
     g.bsum = (unsigned int*)w; w += 4 * (g.nb + 1);
-    g.bbpart = (unsigned int*)w; w += 4 * 6 * BBOX_BLOCKS;
-    g.cell_of = (unsigned int*)w; w += 4 * n2;
+    g.bbpart = (unsigned int*)w; w += 4 * 6 * BBOX_MAX_PARTS;
     g.unresolved = (unsigned int*)w; w += 4 * nq;
     w = (char*)(((uintptr_t)w + 63) & ~(uintptr_t)63);
     g.sorted = (float4*)w;
@@ -621,17 +752,16 @@ __global__ void k_grid_reset_unresolved(GridInfo* gi) { gi->n_unresolved = 0; }
 
 // n2: number of reference points, or -- with n2_dev != NULL -- their CAPACITY (the live count is read on the device)
 static void grid_build(const float* p2, int64_t n2, const long long* n2_dev, const GridWs& g, hipStream_t st, int cells = 0) {
-    const int64_t nscan = g.nc + 1;
-    const int gp = (int)((n2 + KT - 1) / KT > 2048 ? 2048 : (n2 + KT - 1) / KT);
-    hipLaunchKernelGGL(k_grid_init, dim3(2048), dim3(256), 0, st, g.gi, g.counts, g.fill, g.nc);
-    const int bb_blocks = gp > BBOX_BLOCKS ? BBOX_BLOCKS : gp;
-    hipLaunchKernelGGL(k_grid_bbox, dim3(bb_blocks), dim3(KT), 0, st, p2, n2, n2_dev, g.bbpart);
+    const int gp = (int)((n2 + KT - 1) / KT > 4096 ? 4096 : (n2 + KT - 1) / KT);
+    const int bb_blocks = gp > BBOX_MAX_PARTS ? BBOX_MAX_PARTS : gp;
+    hipLaunchKernelGGL(k_grid_bbox, dim3(bb_blocks), dim3(KT), 0, st, p2, n2, n2_dev, g.bbpart, (int)(((uintptr_t)p2 & 15) == 0));
     hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(BBOX_BLOCKS), 0, st, g.gi, g.bbpart, bb_blocks, grid_max_for(n2), n2_dev, (long long)n2, cells);
-    hipLaunchKernelGGL(k_grid_count, dim3(gp), dim3(KT), 0, st, p2, n2, n2_dev, g.gi, g.cell_of, g.counts);
-    hipLaunchKernelGGL(k_scan_blocksum, dim3(g.nb), dim3(KT), 0, st, g.counts, nscan, g.bsum);
-    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, g.bsum, g.nb);
-    hipLaunchKernelGGL(k_scan_apply, dim3(g.nb), dim3(KT), 0, st, g.counts, nscan, g.bsum, g.starts);
-    hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(KT), 0, st, p2, n2, n2_dev, g.cell_of, g.starts, g.fill, g.sorted);
+    hipLaunchKernelGGL(k_grid_zero, dim3(2048), dim3(256), 0, st, g.gi, g.counts);
+    hipLaunchKernelGGL(k_grid_count, dim3(gp), dim3(KT), 0, st, p2, n2, n2_dev, g.gi, g.counts);
+    hipLaunchKernelGGL(k_scan_blocksum, dim3(g.nb), dim3(KT), 0, st, g.counts, g.gi, g.bsum);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, g.bsum, g.gi);
+    hipLaunchKernelGGL(k_scan_apply, dim3(g.nb), dim3(KT), 0, st, g.counts, g.gi, g.bsum, g.starts);
+    hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(KT), 0, st, p2, n2, n2_dev, g.gi, g.starts, g.counts, g.sorted);
 }
 
 static void grid_query(const float* p1, int64_t n1, const GridWs& g, float* dists, long long* idx, hipStream_t st, int row_len = 0,
@@ -643,7 +773,7 @@ static void grid_query(const float* p1, int64_t n1, const GridWs& g, float* dist
     // one WAVE per unresolved query: 1024 workgroups (4096 waves) suit the refinement queries, of which a few per cent stay unresolved; a small
     // query set that is mostly unresolved (frame-to-model odometry while the pose is still wrong: 19 200 queries, decimetres off the targets)
     // gets a wave per query instead of 2-5 queries per wave in sequence -- idle workgroups leave at once
-    const int64_t rest_blocks = n1 <= 65536 ? (n1 + 3) / 4 : 1024;
+    const int64_t rest_blocks = n1 <= 65536 ? (n1 + 3) / 4 : 2048;
     hipLaunchKernelGGL(k_knn1_rest, dim3((unsigned)(rest_blocks < 1024 ? 1024 : (rest_blocks > 8192 ? 8192 : rest_blocks))), dim3(KT), 0, st, p1, g.gi, g.starts,
                        g.sorted, g.unresolved, dists, idx);
 }

@@ -59,7 +59,7 @@ class RefineStepPlan:
         self.alpha = torch.empty(1, H, W, **f)
         self.moved, self.g_moved, self.g_cloud = (torch.empty(self.N, 3, **f) for _ in range(3))
         self.nn_d = torch.empty(self.N, **f)
-        self.nn_idx = torch.empty(self.N, device=self.dev, dtype=torch.int64)
+        self.nn_idx = torch.full((self.N,), -1, device=self.dev, dtype=torch.int64)     # -1 = no candidate (the first query of a run)
         self.l3 = torch.zeros(3, **f)                               # {mean nearest-neighbour distance, #valid rows, weight / #valid}
         self.g_nn = torch.empty(self.N, **f)
         self.g3 = torch.zeros(1, 1, H, W, **f)
@@ -170,7 +170,9 @@ class RefineStepPlan:
         L.call("e2e_vertex_normal_maps", L.ptr(d), L.ptr(self.K), L.ptr(self.pose_tgt), float(self.alpha_den), L.ptr(self.V), L.ptr(self.Nm), L.ptr(self.Vg),
                L.ptr(self.Ng), L.ptr(self.alpha), 1, self.H, self.W, st)
         L.call("e2e_transform_points", L.ptr(self.Vg), L.ptr(self.T), L.ptr(self.moved), N, 0, st)
-        # steps 2 and 3 of a keyframe: the previous step's neighbours (same pixels, same map) bound the search from the start
+        # the previous query's neighbours bound the search from the start: steps 2 and 3 of a keyframe ask about the same pixels against the
+        # same map; the FIRST step of a keyframe inherits the last answers of the keyframe before (a neighbouring view: the same pixel looks at
+        # a point a few centimetres away; map rows are never removed, so the index still names a real point -- all the bound needs)
         index.query(self.moved, N, self.nn_d, self.nn_idx, st, row_len=self.W, warm=self.nn_idx if warm else None)
         L.call("e2e_masked_mean_lossgrad", L.ptr(self.nn_d), L.ptr(d), N, self.w_3d, L.ptr(self.l3), L.ptr(self.g_nn), L.ptr(self.ws_aux), st)
         L.call("e2e_knn1_bwd", L.ptr(self.g_nn), L.ptr(self.moved), L.ptr(index.ref), L.ptr(self.nn_idx), N, L.ptr(self.g_moved), st)
@@ -217,7 +219,7 @@ class RefineStepPlan:
         # the 3-D loss against a RESIDENT index (e2ehip.fusionmap: one buffer per run, map size on the device) has constant launch
         # arguments and rides in the backward graph; any other index object is queried eagerly here
         cap_idx, ikey = None, None
-        warm = use_3d and not first_step                            # steps 2, 3 of a keyframe: same pixels, same map as the step before
+        warm = use_3d                                               # every query starts from the previous one's answers (see _loss3d)
         if use_3d and getattr(knn_index, "resident", False):
             cap_idx, ikey = knn_index, (knn_index.ws.data_ptr(), warm)
         elif use_3d:
