@@ -615,6 +615,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvArgs a) {
         store_chunk(buf ^ 1, buf ^ 1);                       // chunk c + 1, loaded one step ago
 #pragma unroll
         for (int kk = 0; kk < CB / 4; ++kk) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][kk], fb[buf][kk], acc[0][0], 0, 0, 0);
+        // the staging work of the step -- the scalar bookkeeping of the weight-tile loads, the loads, the LDS stores -- is dealt out BETWEEN
+        // the MFMAs of the first half: hipcc's own order issued most of it ahead of the first MFMA (round-4 disassembly; +1.5 % steps/s,
+        // profiles/r04_gemm_interleave_ab.txt).  Issuing the first two or four MFMAs ahead of load_chunk as well -- its tap bookkeeping ends in
+        // a wave-uniform branch, i.e. in basic blocks of its own that no MFMA can be scheduled into -- did not pay (205.2 / 202.4 against 205.8).
+#pragma unroll
+        for (int g = 0; g < CB / 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x004, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
@@ -1492,9 +1504,11 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
             const int ys0 = ybase + b_kh[j], xs0 = xbase + b_kw[j];
-            const bool inside = ys0 >= 0 && ys0 < a.Hs && xs0 >= 0 && xs0 < a.Ws;
+            // (bitwise, not short-circuit: `&&` became s_and_saveexec / s_or exec pairs around the later comparisons, and an instruction that
+            //  writes exec is a wall for the instruction scheduler -- the MFMAs of the step could not be moved ahead of the gather arithmetic)
+            const bool inside = ((unsigned)ys0 < (unsigned)a.Hs) & ((unsigned)xs0 < (unsigned)a.Ws);
             const int ys = reflect ? reflect1(ys0, a.Hs) : ys0, xs = reflect ? reflect1(xs0, a.Ws) : xs0;
-            const bool ok = b_conv[j] && b_row < left && (reflect || inside);
+            const bool ok = b_conv[j] & (b_row < left) & (reflect | inside);
             // (offset | out-of-range bit: written as `ok ? offset : OOB` the compiler sinks the offset arithmetic into an exec-masked branch;
             //  a structural zero may carry a negative ys / xs: its offset is garbage and never used)
             const unsigned pix0 = umad24(umad24((unsigned)cur_b, (unsigned)Hl, (unsigned)(ys >> sh)), (unsigned)Wl, (unsigned)(xs >> sh));
@@ -1549,6 +1563,16 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm4(WgradArgs a) {
         store_chunk(buf ^ 1, buf ^ 1);
 #pragma unroll
         for (int kk = 0; kk < CB / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][kk], fb[buf][kk], acc, 0, 0, 0);
+        // the gather's address arithmetic (~100 vector instructions per step), its loads and the LDS stores are dealt out between the MFMAs of the
+        // first half: hipcc's own order issued all of it ahead of the first MFMA of the step (round-4 disassembly)
+#pragma unroll
+        for (int g = 0; g < CB / 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
+            __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
