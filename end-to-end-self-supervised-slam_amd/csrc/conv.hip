@@ -2099,52 +2099,84 @@ __global__ __launch_bounds__(TAP_NT) void k_wgrad3x3_taps(TapWgradArgs a) {
 // to the sum (the folded BatchNorm scale, when the GEMM ran on dA instead of dZ = dA * scale).  Measured alone on this network's
 // shapes (scratch/reduce_bench.hip): 4-8 us against 8-11 us for the scalar-load form on the many-slab layers, equal on the
 // few-slab ones (17 us at 512x512x3x3, where the 9.4 MB scatter dominates).
+// one group of 64 quads: lane e of wave w (of ZL) -- `part` is the group's [ZL][64] LDS scratch; every thread of the workgroup calls this the same
+// number of times (two barriers inside)
+template <int ZL>
+__device__ __forceinline__ void wgrad_reduce_group(const float* __restrict__ slabs, int S, int Mpad, int Npad, int Cout, int Cin, int KH, int KW, int has_bias,
+                                                   float* __restrict__ dw, float* __restrict__ dbias, int accumulate, const float* __restrict__ scale,
+                                                   int64_t base, int e, int w, f4v (*part)[64]) {
+    const int Kconv = KH * KW * Cin, Ng = Kconv + (has_bias ? 1 : 0);
+    const int nq = (Ng + 3) / 4;
+    const int64_t totalq = (int64_t)Cout * nq;
+    const int64_t slab_q = (int64_t)Mpad * Npad / 4;
+    const f4v zero = {0.f, 0.f, 0.f, 0.f};
+    const int64_t q = base + e;
+    const bool on = q < totalq;
+    const int m = on ? (int)(q / nq) : 0, n = on ? (int)(q - (int64_t)m * nq) * 4 : 0;
+    const f4v* src = (const f4v*)(slabs + (int64_t)m * Npad + n);
+    f4v sacc = zero;
+    int z = w;
+    for (; z + 3 * ZL < S; z += 4 * ZL) {
+        f4v v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = on ? src[(int64_t)(z + ZL * j) * slab_q] : zero;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sacc += v[j];
+    }
+    for (; z < S; z += ZL) sacc += on ? src[(int64_t)z * slab_q] : zero;
+    part[w][e] = sacc;
+    __syncthreads();
+    if (w == 0 && on) {
+        f4v t = part[0][e];
+#pragma unroll
+        for (int j = 1; j < ZL; ++j) t += part[j][e];
+        if (scale) t *= scale[m];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int nn = n + k;
+            if (nn < Kconv) {
+                const int tap = nn / Cin, ci = nn - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
+                float* d = dw + (((int64_t)m * Cin + ci) * KH + kh) * KW + kw;
+                *d = accumulate ? *d + t[k] : t[k];
+            } else if (nn == Kconv && dbias) {
+                dbias[m] = accumulate ? dbias[m] + t[k] : t[k];
+            }
+        }
+    }
+    __syncthreads();
+}
+
 template <int ZL>
 __global__ __launch_bounds__(64 * ZL) void k_wgrad_reduce(const float* __restrict__ slabs, int S, int Mpad, int Npad, int Cout, int Cin,
                                                          int KH, int KW, int has_bias, float* __restrict__ dw, float* __restrict__ dbias,
                                                          int accumulate, const float* __restrict__ scale) {
     __shared__ f4v part[ZL][64];
-    const int Kconv = KH * KW * Cin, Ng = Kconv + (has_bias ? 1 : 0);
-    const int nq = (Ng + 3) / 4;
-    const int64_t totalq = (int64_t)Cout * nq;
+    const int64_t totalq = (int64_t)Cout * ((KH * KW * Cin + (has_bias ? 1 : 0) + 3) / 4);
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < totalq; base += (int64_t)gridDim.x * 64)
+        wgrad_reduce_group<ZL>(slabs, S, Mpad, Npad, Cout, Cin, KH, KW, has_bias, dw, dbias, accumulate, scale, base, threadIdx.x & 63, threadIdx.x >> 6, part);
+}
+
+// The slab reductions of MANY layers in one launch (e2e_wgrad_reduce_batched): a backward pass of the depth network ends ~30 backward-weight GEMMs
+// with a reduction launch of 5 - 15 us each, most of it launch latency and an almost empty GPU (a layer's dW is 10^4 - 10^6 floats) -- 0.29 ms of
+// a 4.9 ms step.  Deferred to the end of the pass they are one grid that fills the chip.  A work item is one workgroup-load of a layer's quads:
+// 64 quads shared by 8 waves (zl = 8, layers with >= 8 slabs) or 4 x 64 quads by 2 waves each (zl = 2), i.e. the SAME association of the sum as
+// the per-layer launch -- the results are bit-identical to e2e_conv2d_bwd_weight_scaled.
+__global__ __launch_bounds__(512) void k_wgrad_reduce_batched(const e2e_wgrad_reduce_desc* __restrict__ d, int n, long long total_items) {
+    __shared__ f4v part[8][64];
     const int e = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t slab_q = (int64_t)Mpad * Npad / 4;
-    const f4v zero = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t base = (int64_t)blockIdx.x * 64; base < totalq; base += (int64_t)gridDim.x * 64) {
-        const int64_t q = base + e;
-        const bool on = q < totalq;
-        const int m = on ? (int)(q / nq) : 0, n = on ? (int)(q - (int64_t)m * nq) * 4 : 0;
-        const f4v* src = (const f4v*)(slabs + (int64_t)m * Npad + n);
-        f4v sacc = zero;
-        int z = w;
-        for (; z + 3 * ZL < S; z += 4 * ZL) {
-            f4v v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = on ? src[(int64_t)(z + ZL * j) * slab_q] : zero;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sacc += v[j];
+    for (long long item = blockIdx.x; item < total_items; item += gridDim.x) {
+        int lo = 0, hi = n - 1;                                   // last descriptor whose first_item <= item (workgroup-uniform)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (d[mid].first_item <= item) lo = mid; else hi = mid - 1;
         }
-        for (; z < S; z += ZL) sacc += on ? src[(int64_t)z * slab_q] : zero;
-        part[w][e] = sacc;
-        __syncthreads();
-        if (w == 0 && on) {
-            f4v t = part[0][e];
-#pragma unroll
-            for (int j = 1; j < ZL; ++j) t += part[j][e];
-            if (scale) t *= scale[m];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int nn = n + k;
-                if (nn < Kconv) {
-                    const int tap = nn / Cin, ci = nn - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
-                    float* d = dw + (((int64_t)m * Cin + ci) * KH + kh) * KW + kw;
-                    *d = accumulate ? *d + t[k] : t[k];
-                } else if (nn == Kconv && dbias) {
-                    dbias[m] = accumulate ? dbias[m] + t[k] : t[k];
-                }
-            }
-        }
-        __syncthreads();
+        const e2e_wgrad_reduce_desc D = d[lo];
+        const long long local = item - D.first_item;
+        if (D.zl == 8)
+            wgrad_reduce_group<8>(D.slabs, D.S, D.Mpad, D.Npad, D.Cout, D.Cin, D.KH, D.KW, D.has_bias, D.dw, D.dbias, D.accumulate, D.scale, local * 64, e, w, part);
+        else
+            wgrad_reduce_group<2>(D.slabs, D.S, D.Mpad, D.Npad, D.Cout, D.Cin, D.KH, D.KW, D.has_bias, D.dw, D.dbias, D.accumulate, D.scale,
+                                  (local * 4 + (w >> 1)) * 64, e, w & 1, part + 2 * (w >> 1));
     }
 }
 
@@ -2980,7 +3012,7 @@ int64_t e2e_conv2d_wgrad_workspace_floats(int B, int Ho, int Wo, int Cin, int Co
 
 static int bwd_weight_impl(const float* dz, const float* src0, const float* src1, int C1, int up, float* dw, float* dbias, float* workspace, int B,
                            int Hs, int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride, int pad, int pad_mode, int accumulate,
-                           float in_sub, float in_mul, const float* out_scale, void* stream, int wg_target = 0) {
+                           float in_sub, float in_mul, const float* out_scale, void* stream, int wg_target = 0, e2e_wgrad_reduce_desc* defer = nullptr) {
     const bool tuned = wg_target != 0;
     if (!tuned) wg_target = WGRAD_TARGET;
     E2E_REQUIRE(dz && src0 && dw && workspace && B > 0 && Cin > 0 && Cout > 0, E2E_ERR_ARG, "e2e_conv2d_bwd_weight: bad argument");
@@ -2995,14 +3027,27 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
     // lean VEC-4 kernel: 32 pixels per chunk; needs Cout % 4 == 0, 32-bit offsets and image rows of at least 8 pixels
     const bool lean = vec == 4 && Cout % 4 == 0 && Wo >= 8 && (int64_t)B * Hs * Ws * Cin * 4 < (1ll << 31) && P * Cout * 4 < (1ll << 31) && P < (1ll << 24);
     hipStream_t st = (hipStream_t)stream;
+    // the slab reduction that ends every path: launched here, or -- `defer` -- described for e2e_wgrad_reduce_batched
+    auto reduce = [&](int S, int Mpad, int Npad, int zl) {
+        if (defer) {
+            *defer = e2e_wgrad_reduce_desc{workspace, dw, dbias, out_scale, S, Mpad, Npad, Cout, Cin, KH, KW, a.has_bias, accumulate, zl, 0};
+            return;
+        }
+        const int64_t tq = (int64_t)Cout * ((a.Ngemm + 3) / 4);
+        if (zl == 8)
+            hipLaunchKernelGGL((k_wgrad_reduce<8>), dim3(egrid(tq * 4)), dim3(512), 0, st, workspace, S, Mpad, Npad, Cout, Cin, KH, KW, a.has_bias, dw, dbias,
+                               accumulate, out_scale);
+        else
+            hipLaunchKernelGGL((k_wgrad_reduce<2>), dim3(egrid(tq * 4)), dim3(128), 0, st, workspace, S, Mpad, Npad, Cout, Cin, KH, KW, a.has_bias, dw, dbias,
+                               accumulate, out_scale);
+    };
     // the RGB stem: patch kernel + the common slab reduction
     if (KH == 7 && KW == 7 && stride == 2 && pad == 3 && pad_mode == 0 && Cin == 3 && Cout == 64 && C1 == Cin && up == 1 && !dbias &&
         Ho == (Hs + 6 - 7) / 2 + 1 && Wo == (Ws + 6 - 7) / 2 + 1) {
         const int nxg = ((Wo + 31) / 32 + 1) / 2, ny = (Ho + 3) / 4;
         StemWgradArgs ta{dz, src0, workspace, B, Hs, Ws, Ho, Wo, 2, nxg, in_sub, in_mul};
         hipLaunchKernelGGL(k_wgrad7x7_stem, dim3(nxg, ny, B), dim3(256), 0, st, ta);
-        hipLaunchKernelGGL((k_wgrad_reduce<8>), dim3(egrid((int64_t)64 * 37 * 4)), dim3(512), 0, st, workspace, B * ny * nxg, 64, 148, 64, 3, 7, 7, 0, dw, dbias,
-                           accumulate, out_scale);
+        reduce(B * ny * nxg, 64, 148, 8);
         E2E_LAUNCH_CHECK("e2e_conv2d_bwd_weight");
         return E2E_OK;
     }
@@ -3014,9 +3059,7 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
         const dim3 tg((unsigned)t.nxg, (unsigned)t.ny, (unsigned)(B * (Cin / 16)));
         if (Cout == 32) hipLaunchKernelGGL((k_wgrad3x3_thin<2>), tg, dim3(256), 0, st, ta);
         else hipLaunchKernelGGL((k_wgrad3x3_thin<1>), tg, dim3(256), 0, st, ta);
-        const int64_t tq = (int64_t)Cout * ((a.Ngemm + 3) / 4);
-        hipLaunchKernelGGL((k_wgrad_reduce<8>), dim3(egrid(tq * 4)), dim3(512), 0, st, workspace, (int)t.S, Cout, t.npad, Cout, Cin, KH, KW, a.has_bias, dw, dbias,
-                           accumulate, out_scale);
+        reduce((int)t.S, Cout, t.npad, 8);
         E2E_LAUNCH_CHECK("e2e_conv2d_bwd_weight");
         return E2E_OK;
     }
@@ -3031,13 +3074,7 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
         const dim3 tg((unsigned)(Cin / 32), (unsigned)(Cout / 32), (unsigned)t.S);
         if (a.has_bias) hipLaunchKernelGGL(k_wgrad3x3_taps<true>, tg, dim3(TAP_NT), 0, st, ta);
         else hipLaunchKernelGGL(k_wgrad3x3_taps<false>, tg, dim3(TAP_NT), 0, st, ta);
-        const int64_t tq = (int64_t)Cout * ((a.Ngemm + 3) / 4);
-        if (t.S >= 8)
-            hipLaunchKernelGGL((k_wgrad_reduce<8>), dim3(egrid(tq * 4)), dim3(512), 0, st, workspace, t.S, Cout, t.Npad, Cout, Cin, KH, KW, a.has_bias, dw, dbias,
-                               accumulate, out_scale);
-        else
-            hipLaunchKernelGGL((k_wgrad_reduce<2>), dim3(egrid(tq * 4)), dim3(128), 0, st, workspace, t.S, Cout, t.Npad, Cout, Cin, KH, KW, a.has_bias, dw, dbias,
-                               accumulate, out_scale);
+        reduce(t.S, Cout, t.Npad, t.S >= 8 ? 8 : 2);
         E2E_LAUNCH_CHECK("e2e_conv2d_bwd_weight");
         return E2E_OK;
     }
@@ -3068,13 +3105,7 @@ static int bwd_weight_impl(const float* dz, const float* src0, const float* src1
         if (vec == 4) hipLaunchKernelGGL((k_wgrad_gemm<2, 2, 4>), g, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_wgrad_gemm<2, 2, 1>), g, dim3(256), 0, st, a);
     }
-    const int64_t quads = (int64_t)Cout * ((a.Ngemm + 3) / 4);
-    if (Sz >= 8)
-        hipLaunchKernelGGL((k_wgrad_reduce<8>), dim3(egrid(quads * 4)), dim3(512), 0, st, workspace, Sz, a.Mpad, a.Npad, Cout, Cin,
-                           KH, KW, a.has_bias, dw, dbias, accumulate, out_scale);
-    else
-        hipLaunchKernelGGL((k_wgrad_reduce<2>), dim3(egrid(quads * 4)), dim3(128), 0, st, workspace, Sz, a.Mpad, a.Npad, Cout, Cin,
-                           KH, KW, a.has_bias, dw, dbias, accumulate, out_scale);
+    reduce(Sz, a.Mpad, a.Npad, Sz >= 8 ? 8 : 2);
     E2E_LAUNCH_CHECK("e2e_conv2d_bwd_weight");
     return E2E_OK;
 }
@@ -3091,6 +3122,41 @@ int e2e_conv2d_bwd_weight_scaled(const float* da, const float* out_scale, const 
                                  int stride, int pad, int pad_mode, int accumulate, float in_sub, float in_mul, void* stream) {
     return bwd_weight_impl(da, src0, src1, C1, up, dw, dbias, workspace, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate,
                            in_sub, in_mul, out_scale, stream);
+}
+
+/* e2e_conv2d_bwd_weight_scaled WITHOUT its final launch: the partial slabs stay in `workspace` (which must stay untouched until the reduction
+ * ran) and *desc_out (HOST memory) describes the reduction left to do.  A caller collects the descriptors of a whole backward pass,
+ * e2e_wgrad_reduce_batch_prepare()s the array, copies it to the device once (shapes, pointers and decompositions are those of a static launch
+ * plan) and ends the pass with ONE e2e_wgrad_reduce_batched launch.  Results are bit-identical to e2e_conv2d_bwd_weight_scaled. */
+int e2e_conv2d_bwd_weight_scaled_deferred(const float* da, const float* out_scale, const float* src0, const float* src1, int C1, int up, float* dw,
+                                          float* dbias, float* workspace, int B, int Hs, int Ws, int Cin, int Cout, int Ho, int Wo, int KH, int KW,
+                                          int stride, int pad, int pad_mode, int accumulate, float in_sub, float in_mul,
+                                          e2e_wgrad_reduce_desc* desc_out, void* stream) {
+    E2E_REQUIRE(desc_out, E2E_ERR_ARG, "e2e_conv2d_bwd_weight_scaled_deferred: desc_out is NULL");
+    return bwd_weight_impl(da, src0, src1, C1, up, dw, dbias, workspace, B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW, stride, pad, pad_mode, accumulate,
+                           in_sub, in_mul, out_scale, stream, 0, desc_out);
+}
+
+/* fills first_item of n descriptors in HOST memory (running total of work items); returns the total, or -1 on a malformed descriptor */
+long long e2e_wgrad_reduce_batch_prepare(e2e_wgrad_reduce_desc* descs_host, int n) {
+    if (!descs_host || n <= 0) return -1;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        e2e_wgrad_reduce_desc& d = descs_host[i];
+        if (!d.slabs || !d.dw || d.S <= 0 || d.Mpad <= 0 || d.Npad <= 0 || d.Npad % 4 || d.Cout <= 0 || d.Cin <= 0 || d.KH <= 0 || d.KW <= 0 || (d.zl != 8 && d.zl != 2))
+            return -1;
+        const long long quads = (long long)d.Cout * ((d.KH * d.KW * d.Cin + (d.has_bias ? 1 : 0) + 3) / 4);
+        d.first_item = total;
+        total += (quads + (d.zl == 8 ? 63 : 255)) / (d.zl == 8 ? 64 : 256);
+    }
+    return total;
+}
+
+int e2e_wgrad_reduce_batched(const e2e_wgrad_reduce_desc* descs_dev, int n, long long total_items, void* stream) {
+    E2E_REQUIRE(descs_dev && n > 0 && total_items > 0, E2E_ERR_ARG, "e2e_wgrad_reduce_batched: bad argument");
+    hipLaunchKernelGGL(k_wgrad_reduce_batched, dim3((unsigned)(total_items < 4096 ? total_items : 4096)), dim3(512), 0, (hipStream_t)stream, descs_dev, n, total_items);
+    E2E_LAUNCH_CHECK("e2e_wgrad_reduce_batched");
+    return E2E_OK;
 }
 
 /* the same through the implicit-GEMM kernels with an explicit number of workgroups to spread the pixel slices over (64 .. 8192; tools/gemm_tune.py).

@@ -106,6 +106,7 @@ class _Conv:
         # adds this layer's gradient to the block input (pre_add) -- no separate accumulate pass; `res_aliased`: the residual tensor
         # has no activation and no other consumer (downsample branch), its gradient buffer IS this layer's
         self.res_via, self.res_aliased, self.pre_from = None, False, None
+        self.reduce_desc = L.WgradReduceDesc()               # filled by every backward-weight launch (identical every time: the plan is static)
 
     def layout_row(self):
         return [self.weight.data_ptr(), self.wf.data_ptr(), self.wb.data_ptr() if self.wb is not None else 0, self.Cout, self.Cin, self.KH, self.KW,
@@ -144,9 +145,11 @@ class _Conv:
                 if s1 is not None:
                     s1.written = True
         st_w = plan.fork(st)
-        L.call("e2e_conv2d_bwd_weight_scaled", L.ptr(g), L.ptr(s.scale), L.ptr(s.src0.t), L.ptr(s.src1.t) if s.src1 is not None else None, s.C1, s.up,
+        # the GEMM leaves its partial slabs in this layer's own workspace; the ~30 slab reductions of a pass are ONE launch at its end
+        # (NetPlan._reduce_weight_gradients): each was 5 - 15 us of launch latency on an almost empty GPU
+        L.call("e2e_conv2d_bwd_weight_scaled_deferred", L.ptr(g), L.ptr(s.scale), L.ptr(s.src0.t), L.ptr(s.src1.t) if s.src1 is not None else None, s.C1, s.up,
                L.ptr(plan.sink(s.weight)), L.ptr(plan.sink(s.bias)) if s.bias is not None else None, L.ptr(s.ws_w), B, s.Hs, s.Ws, s.Cin, s.Cout, s.Ho,
-               s.Wo, s.KH, s.KW, s.stride, s.pad, s.pm, 0, float(s.isub), float(s.imul), st_w)
+               s.Wo, s.KH, s.KW, s.stride, s.pad, s.pm, 0, float(s.isub), float(s.imul), ctypes.byref(s.reduce_desc), st_w)
 
 
 class _Head:
@@ -284,6 +287,8 @@ class NetPlan:
         self.disp = self.head.out                     # (B,H,W,1) NHWC == (B,1,H,W) contiguous
         self._desc = None
         self._desc_key = None
+        self._retired_tables = []
+        self._reduce_tables = {}                             # "late" / "early" -> (descriptor bytes, device copy, work items)
 
     def _add(self, op):
         self.ops.append(op)
@@ -373,7 +378,7 @@ class NetPlan:
         if self._side is not None:
             self._side.synchronize()
         torch.cuda.current_stream(self.dev).synchronize()
-        self.ops, self._sinks, self._desc = [], {}, None
+        self.ops, self._sinks, self._desc, self._reduce_tables = [], {}, None, {}
 
     # -- the two passes ------------------------------------------------------------------------------------------------
     def forward(self, frames=None):
@@ -419,6 +424,7 @@ class NetPlan:
         for op in reversed(self.ops[self.split_index:]):
             op.bwd(self, st)
         self.join()
+        self._reduce_weight_gradients("late", self.ops[self.split_index:])
         # which gradient buffers hold a contribution at the hand-over point: the second half must start from exactly this state however
         # often either half is executed (the data-parallel step runs each half once eagerly and once more under graph capture)
         self._written_after_late = [op.out.written for op in self.ops]
@@ -435,6 +441,29 @@ class NetPlan:
         for op in reversed(self.ops[:self.split_index]):
             op.bwd(self, st)
         self.join()
+        self._reduce_weight_gradients("early", self.ops[:self.split_index])
+
+    def _reduce_weight_gradients(self, which, ops):
+        """ONE launch for the slab reductions the backward-weight GEMMs of `ops` deferred (e2e_wgrad_reduce_batched).  The descriptor table
+        lives on the device; it is rebuilt when a descriptor changed (the optimiser re-homed a gradient sink) -- never under stream capture,
+        where the table the graph would keep pointing at must already exist (a plan runs eagerly at least once before it is captured)."""
+        convs = [op for op in ops if isinstance(op, _Conv)]
+        if not convs:
+            return
+        arr = (L.WgradReduceDesc * len(convs))(*[op.reduce_desc for op in convs])
+        total = L.load().e2e_wgrad_reduce_batch_prepare(arr, len(convs))
+        if total <= 0:
+            raise RuntimeError("launch plan: malformed backward-weight reduction descriptor")
+        raw = bytes(arr)
+        held = self._reduce_tables.get(which)
+        if held is None or held[0] != raw:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("launch plan: the backward-weight reduction table changed under stream capture; run the plan eagerly once first")
+            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.dev)
+            if held is not None:
+                self._retired_tables.append(held[1])        # a graph captured earlier may still name the old table: it stays allocated
+            held = self._reduce_tables[which] = (raw, table, total)
+        L.call("e2e_wgrad_reduce_batched", L.ptr(held[1]), len(convs), held[2], L.stream())
 
     def split_offset(self, flat):
         """Offset in the flat parameter / gradient bucket where the parameters of ops[split_index:] begin; checks that they ARE the

@@ -526,6 +526,26 @@ int e2e_conv2d_bwd_weight_scaled(const float* da, const float* out_scale, const 
                                  int Wo, int KH, int KW, int stride, int pad, int pad_mode,
                                  int accumulate, float in_sub, float in_mul, void* stream);
 
+/* The slab reduction that ends a backward-weight call, as data (see e2e_conv2d_bwd_weight_scaled_deferred): the reference has no counterpart --
+ * torch.autograd runs cuDNN's backward-filter per layer (loss.backward(), online_adaption.py:323) -- this is launch economy of the static plan. */
+typedef struct e2e_wgrad_reduce_desc {
+    const float* slabs;     /* S partial slabs [Mpad][Npad] */
+    float* dw;              /* (Cout,Cin,KH,KW) */
+    float* dbias;           /* (Cout) or NULL */
+    const float* scale;     /* per-output-channel factor or NULL */
+    int S, Mpad, Npad, Cout, Cin, KH, KW, has_bias, accumulate;
+    int zl;                 /* 8 or 2: waves that share the slabs of one group of 64 quads (fixes the association of the sum) */
+    long long first_item;   /* filled by e2e_wgrad_reduce_batch_prepare */
+} e2e_wgrad_reduce_desc;
+int e2e_conv2d_bwd_weight_scaled_deferred(const float* da, const float* out_scale, const float* src0,
+                                          const float* src1, int C1, int up, float* dw, float* dbias,
+                                          float* workspace, int B, int Hs, int Ws, int Cin, int Cout, int Ho,
+                                          int Wo, int KH, int KW, int stride, int pad, int pad_mode,
+                                          int accumulate, float in_sub, float in_mul,
+                                          e2e_wgrad_reduce_desc* desc_out_host, void* stream);
+long long e2e_wgrad_reduce_batch_prepare(e2e_wgrad_reduce_desc* descs_host, int n);
+int e2e_wgrad_reduce_batched(const e2e_wgrad_reduce_desc* descs_dev, int n, long long total_items, void* stream);
+
 /* ResNet stem max-pool, nn.MaxPool2d(3, 2, 1) (networks.py:53 -> torchvision resnet.maxpool): x (B,H,W,C) NHWC ->
  * y (B,(H-1)/2+1,(W-1)/2+1,C).  The backward keeps no index tensor: every input element re-derives the first maximum
  * (ATen's scan order) of the <= 4 windows that contain it; accumulate != 0 adds to dx, mul_relu != 0 multiplies the

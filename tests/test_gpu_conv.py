@@ -195,3 +195,63 @@ def test_streamk_decomposition(G):
         for a, b, name in [(y, yr, "y")] + [(a, b, f"d_in{i}") for i, (a, b) in enumerate(zip(gs, gr))]:
             e = ((a.double() - b).abs().max() / (b.abs().max() + 1e-30)).item()
             assert e < 5e-5, f"G={G} {name} {Cin}->{Cout} {pm}: {e:.2e}"
+
+
+def test_deferred_slab_reductions_in_one_launch_equal_the_per_layer_calls():
+    """e2e_conv2d_bwd_weight_scaled_deferred + ONE e2e_wgrad_reduce_batched over several layers (what a NetPlan backward pass ends with) writes
+    exactly the bits e2e_conv2d_bwd_weight_scaled writes layer by layer: the batched kernel keeps each layer's association of the slab sum
+    (8 waves per group of quads from 8 slabs on, 2 below).  Covers the implicit-GEMM kernels with many and with few slabs, the 16-output-channel
+    kernel, the thin 3x3 patch kernel, the RGB stem, a concat layer, bias columns and the folded-BatchNorm scale."""
+    import ctypes
+    from e2ehip import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    # B, Cin, C1, up, Hs, Ws, Cout, k, stride, pad, pad_mode(1 = reflect), bias, scale
+    layers = [(2, 64, 64, 1, 60, 80, 64, 3, 1, 1, 0, False, True),        # many slabs (zl = 8)
+              (2, 256, 256, 1, 8, 10, 512, 3, 2, 1, 0, False, True),      # few slabs (zl = 2)
+              (2, 3, 3, 1, 64, 96, 64, 7, 2, 3, 0, False, True),          # RGB stem patch kernel
+              (1, 96, 32, 2, 32, 48, 32, 3, 1, 1, 1, True, False),        # thin 3x3, upsample + skip concat, bias column
+              (1, 32, 32, 1, 40, 56, 16, 3, 1, 1, 1, True, False),        # 16 output channels
+              (2, 128, 128, 1, 15, 20, 256, 1, 1, 0, 0, True, False)]     # 1x1
+    calls, descs, outs_ref, outs_def, keep = [], [], [], [], []
+    for (B, Cin, C1, up, Hs, Ws, Cout, k, stride, pad, pm, has_bias, has_scale) in layers:
+        Ho, Wo = (Hs + 2 * pad - k) // stride + 1, (Ws + 2 * pad - k) // stride + 1
+        src0 = torch.randn(B, Hs // up, Ws // up, C1, generator=g).to(DEV)
+        src1 = torch.randn(B, Hs, Ws, Cin - C1, generator=g).to(DEV) if C1 < Cin else None
+        da = torch.randn(B, Ho, Wo, Cout, generator=g).to(DEV)
+        scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV) if has_scale else None
+        n_ws = lib.e2e_conv2d_wgrad_workspace_floats(B, Ho, Wo, Cin, Cout, k, k, 1 if has_bias else 0)
+        res = []
+        for deferred in (False, True):
+            dw = torch.full((Cout, Cin, k, k), float("nan"), device=DEV)
+            db = torch.full((Cout,), float("nan"), device=DEV) if has_bias else None
+            ws = torch.empty(n_ws, device=DEV)
+            args = [L.ptr(da), L.ptr(scale), L.ptr(src0), L.ptr(src1), C1, up, L.ptr(dw), L.ptr(db), L.ptr(ws), B, Hs, Ws, Cin, Cout, Ho, Wo, k, k, stride, pad, pm, 0,
+                    0.45 if Cin == 3 else 0.0, 1 / 0.225 if Cin == 3 else 1.0]
+            if deferred:
+                d = L.WgradReduceDesc()
+                L.call("e2e_conv2d_bwd_weight_scaled_deferred", *args, ctypes.byref(d), L.stream())
+                descs.append(d)
+            else:
+                L.call("e2e_conv2d_bwd_weight_scaled", *args, L.stream())
+            res.append((dw, db))
+            keep += [ws, dw, db]
+        outs_ref.append(res[0])
+        outs_def.append(res[1])
+        keep += [src0, src1, da, scale]
+    assert {d.zl for d in descs} == {2, 8}
+    arr = (L.WgradReduceDesc * len(descs))(*descs)
+    total = lib.e2e_wgrad_reduce_batch_prepare(arr, len(descs))
+    assert total > 0 and arr[0].first_item == 0 and all(arr[i].first_item < arr[i + 1].first_item for i in range(len(descs) - 1))
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    assert torch.isnan(outs_def[0][0]).all()                       # nothing was reduced yet
+    L.call("e2e_wgrad_reduce_batched", L.ptr(table), len(descs), total, L.stream())
+    torch.cuda.synchronize()
+    for (dw_r, db_r), (dw_d, db_d) in zip(outs_ref, outs_def):
+        assert torch.isfinite(dw_r).all() and torch.equal(dw_r, dw_d)
+        if db_r is not None:
+            assert torch.equal(db_r, db_d)
+    bad = (L.WgradReduceDesc * 1)(L.WgradReduceDesc())
+    assert lib.e2e_wgrad_reduce_batch_prepare(bad, 1) == -1
+    with pytest.raises(L.E2EError):
+        L.call("e2e_wgrad_reduce_batched", None, 1, 1, L.stream())
