@@ -337,6 +337,32 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd_idx(const float* __restrict
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Many device-to-device copies in one launch (e2e_copy_batched).  The forward-reuse of the refinement loop moves every layer's activations of
+// one image from batch slot 1 to slot 0 at the start of a keyframe (NetPlan.move_slot): ~70 copies of 0.04 - 10 MB, 5 us each as separate
+// copy-engine / blit launches.  A work item is 16 KB of one copy; a descriptor table in device memory says where each copy's items start.
+// ---------------------------------------------------------------------------------------------------------------------
+#define COPY_ITEM_BYTES 16384
+__global__ __launch_bounds__(256) void k_copy_batched(const e2e_copy_desc* __restrict__ d, int n, long long total_items) {
+    for (long long item = blockIdx.x; item < total_items; item += gridDim.x) {
+        int lo = 0, hi = n - 1;                                   // last descriptor whose first_item <= item (workgroup-uniform)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (d[mid].first_item <= item) lo = mid; else hi = mid - 1;
+        }
+        const long long off = (item - d[lo].first_item) * COPY_ITEM_BYTES, left = d[lo].bytes - off;
+        const uint4* s = (const uint4*)((const char*)d[lo].src + off);
+        uint4* t = (uint4*)((char*)d[lo].dst + off);
+        const int nq = (int)((left < COPY_ITEM_BYTES ? left : COPY_ITEM_BYTES) / 16);
+        uint4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if ((int)threadIdx.x + j * 256 < nq) v[j] = s[threadIdx.x + j * 256];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if ((int)threadIdx.x + j * 256 < nq) t[threadIdx.x + j * 256] = v[j];
+    }
+}
+
 extern "C" {
 
 int e2e_maxpool3x3s2_fwd_idx(const float* x, float* y, unsigned char* argmax, int B, int H, int W, int C, void* stream) {
@@ -420,6 +446,27 @@ int e2e_upsample2_concat(const float* x, const float* skip, float* y, int B, int
     hipLaunchKernelGGL(k_upsample2_concat, dim3(mgrid((int64_t)B * 4 * h * w * (C1 + C2))), dim3(256), 0, (hipStream_t)stream, x, skip, y, B, h, w,
                        C1, C2);
     E2E_LAUNCH_CHECK("e2e_upsample2_concat");
+    return E2E_OK;
+}
+
+/* fills first_item of n descriptors in HOST memory; returns the total number of work items, or -1 on a malformed descriptor
+ * (NULL pointer, size not a positive multiple of 16, pointer not 16-byte aligned) */
+long long e2e_copy_batch_prepare(e2e_copy_desc* descs_host, int n) {
+    if (!descs_host || n <= 0) return -1;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        e2e_copy_desc& d = descs_host[i];
+        if (!d.src || !d.dst || d.bytes <= 0 || d.bytes % 16 || ((uintptr_t)d.src & 15) || ((uintptr_t)d.dst & 15)) return -1;
+        d.first_item = total;
+        total += (d.bytes + COPY_ITEM_BYTES - 1) / COPY_ITEM_BYTES;
+    }
+    return total;
+}
+
+int e2e_copy_batched(const e2e_copy_desc* descs_dev, int n, long long total_items, void* stream) {
+    E2E_REQUIRE(descs_dev && n > 0 && total_items > 0, E2E_ERR_ARG, "e2e_copy_batched: bad argument");
+    hipLaunchKernelGGL(k_copy_batched, dim3((unsigned)(total_items < 8192 ? total_items : 8192)), dim3(256), 0, (hipStream_t)stream, descs_dev, n, total_items);
+    E2E_LAUNCH_CHECK("e2e_copy_batched");
     return E2E_OK;
 }
 

@@ -27,6 +27,11 @@ class WgradReduceDesc(ctypes.Structure):
                [(n, c_int) for n in ("S", "Mpad", "Npad", "Cout", "Cin", "KH", "KW", "has_bias", "accumulate", "zl")] + [("first_item", ctypes.c_longlong)]
 
 
+class CopyDesc(ctypes.Structure):
+    """e2e_copy_desc (include/e2eslam.h)."""
+    _fields_ = [("src", c_fp), ("dst", c_fp), ("bytes", ctypes.c_longlong), ("first_item", ctypes.c_longlong)]
+
+
 class E2EError(RuntimeError):
     pass
 
@@ -128,6 +133,8 @@ SIGNATURES = {
     "e2e_conv2d_bwd_weight_scaled_deferred": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp] + [c_int] * 13 + [c_f32, c_f32, ctypes.POINTER(WgradReduceDesc), c_fp],
     "e2e_wgrad_reduce_batch_prepare": [ctypes.POINTER(WgradReduceDesc), c_int],
     "e2e_wgrad_reduce_batched": [c_fp, c_int, ctypes.c_longlong, c_fp],
+    "e2e_copy_batch_prepare": [ctypes.POINTER(CopyDesc), c_int],
+    "e2e_copy_batched": [c_fp, c_int, ctypes.c_longlong, c_fp],
     "e2e_head_bwd_act": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp],
     "e2e_conv2d_act_bwd_acc": [c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_int, c_fp],
     "e2e_conv2d_gather_adjoint": [c_fp] + [c_int] * 7 + [c_fp, c_fp, c_int, c_int, c_fp],
@@ -161,7 +168,7 @@ _RESTYPE = {"e2e_last_error": ctypes.c_char_p, "e2e_warp_photo_workspace_floats"
             "e2e_depth_scale_workspace_bytes": c_i64, "e2e_reduce_workspace_floats": c_i64,
             "e2e_conv2d_wgrad_workspace_floats": c_i64, "e2e_conv2d_wgrad_tuned_workspace_floats": c_i64, "e2e_conv_tuned_workspace_floats": c_i64, "e2e_conv2d_splitk_workspace_floats": c_i64, "e2e_conv2d_bwd_data_workspace_floats": c_i64,
             "e2e_head_workspace_floats": c_i64, "e2e_icp_workspace_bytes": c_i64, "e2e_icp_state_doubles": c_i64, "e2e_aux_workspace_floats": c_i64,
-            "e2e_affine_bwd_workspace_floats": c_i64, "e2e_wgrad_reduce_batch_prepare": ctypes.c_longlong}
+            "e2e_affine_bwd_workspace_floats": c_i64, "e2e_wgrad_reduce_batch_prepare": ctypes.c_longlong, "e2e_copy_batch_prepare": ctypes.c_longlong}
 
 _lib = None
 

@@ -288,6 +288,7 @@ class NetPlan:
         self._desc = None
         self._desc_key = None
         self._retired_tables = []
+        self._move_tables = {}                               # (src slot, dst slot) -> (copy descriptor table on the device, copies, work items)
         self._reduce_tables = {}                             # "late" / "early" -> (descriptor bytes, device copy, work items)
 
     def _add(self, op):
@@ -401,11 +402,28 @@ class NetPlan:
 
     def move_slot(self, src, dst):
         """Everything a backward pass reads of image `src` -- every layer's activations, the max-pool's argmax -- copied to image `dst`
-        (device-to-device copies).  With the input frame of `src` loaded into `dst` as well, slot `dst` then holds a complete forward pass."""
-        for op in self.ops:
-            op.out.t[dst].copy_(op.out.t[src])
-            if isinstance(op, _MaxPool):
-                op.argmax[dst].copy_(op.argmax[src])
+        (ONE launch for the ~70 copies: e2e_copy_batched).  With the input frame of `src` loaded into `dst` as well, slot `dst` then holds a complete forward pass."""
+        held = self._move_tables.get((src, dst))
+        if held is None:
+            if not 0 <= src < self.B or not 0 <= dst < self.B or src == dst:
+                raise ValueError("slots out of range")
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("launch plan: move_slot builds its copy table on first use; run it eagerly once before capturing it")
+            pairs = []
+            for op in self.ops:
+                pairs.append((op.out.t[src], op.out.t[dst]))
+                if isinstance(op, _MaxPool):
+                    pairs.append((op.argmax[src], op.argmax[dst]))
+            if any(a.numel() * a.element_size() % 16 or a.data_ptr() % 16 or b.data_ptr() % 16 for a, b in pairs):
+                for a, b in pairs:                               # (an activation that is not a whole number of 16-byte quads: plain copies)
+                    b.copy_(a)
+                return
+            arr = (L.CopyDesc * len(pairs))(*[L.CopyDesc(a.data_ptr(), b.data_ptr(), a.numel() * a.element_size(), 0) for a, b in pairs])
+            total = L.load().e2e_copy_batch_prepare(arr, len(pairs))
+            if total <= 0:
+                raise RuntimeError("launch plan: malformed copy descriptor")
+            held = self._move_tables[(src, dst)] = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev), len(pairs), total)
+        L.call("e2e_copy_batched", L.ptr(held[0]), held[1], held[2], L.stream())
 
     def backward(self, g_disp=None):
         """g_disp (B,1,H,W): gradient of the loss wrt the disparity (None: already in self.disp.g).  Parameter gradients

@@ -546,6 +546,17 @@ int e2e_conv2d_bwd_weight_scaled_deferred(const float* da, const float* out_scal
 long long e2e_wgrad_reduce_batch_prepare(e2e_wgrad_reduce_desc* descs_host, int n);
 int e2e_wgrad_reduce_batched(const e2e_wgrad_reduce_desc* descs_dev, int n, long long total_items, void* stream);
 
+/* Many device-to-device copies in one launch (launch economy of the static plan; the reference has no counterpart): n descriptors
+ * {src, dst, bytes (a positive multiple of 16, both pointers 16-byte aligned), first_item} in device memory, prepared on the host. */
+typedef struct e2e_copy_desc {
+    const void* src;
+    void* dst;
+    long long bytes;
+    long long first_item;   /* filled by e2e_copy_batch_prepare */
+} e2e_copy_desc;
+long long e2e_copy_batch_prepare(e2e_copy_desc* descs_host, int n);
+int e2e_copy_batched(const e2e_copy_desc* descs_dev, int n, long long total_items, void* stream);
+
 /* ResNet stem max-pool, nn.MaxPool2d(3, 2, 1) (networks.py:53 -> torchvision resnet.maxpool): x (B,H,W,C) NHWC ->
  * y (B,(H-1)/2+1,(W-1)/2+1,C).  The backward keeps no index tensor: every input element re-derives the first maximum
  * (ATen's scan order) of the <= 4 windows that contain it; accumulate != 0 adds to dx, mul_relu != 0 multiplies the

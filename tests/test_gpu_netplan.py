@@ -96,3 +96,28 @@ def test_plan_forward_backward_as_hip_graph():
     assert torch.equal(plan.disp.t, ref_disp)
     for p, r in zip(plan.parameters(), ref):
         assert torch.equal(plan.sink(p), r)
+
+
+def test_batched_copies_equal_plain_copies():
+    """e2e_copy_batched (NetPlan.move_slot: every layer's activations of one image to another batch slot in ONE launch) against tensor copies:
+    sizes from one 16-byte quad to several work items plus a ragged tail; malformed descriptors are refused on the host."""
+    import ctypes
+    from e2ehip import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    sizes = [4, 8, 4096, 4100, 16384 // 4, 16384 // 4 + 4, 3 * 16384 // 4 - 4, 1_000_000, 2_621_440]
+    srcs = [torch.randn(n, generator=g).to(DEV) for n in sizes]
+    dsts = [torch.full((n + 8,), float("nan"), device=DEV) for n in sizes]           # 8 guard floats behind every destination
+    arr = (L.CopyDesc * len(sizes))(*[L.CopyDesc(s.data_ptr(), d.data_ptr(), 4 * n, 0) for s, d, n in zip(srcs, dsts, sizes)])
+    total = lib.e2e_copy_batch_prepare(arr, len(sizes))
+    assert total == sum((4 * n + 16383) // 16384 for n in sizes)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    L.call("e2e_copy_batched", L.ptr(table), len(sizes), total, L.stream())
+    torch.cuda.synchronize()
+    for s, d, n in zip(srcs, dsts, sizes):
+        assert torch.equal(d[:n], s) and torch.isnan(d[n:]).all()
+    for bad in (L.CopyDesc(srcs[0].data_ptr(), dsts[0].data_ptr(), 12, 0), L.CopyDesc(srcs[0].data_ptr() + 4, dsts[0].data_ptr(), 16, 0),
+                L.CopyDesc(None, dsts[0].data_ptr(), 16, 0), L.CopyDesc(srcs[0].data_ptr(), dsts[0].data_ptr(), 0, 0)):
+        assert lib.e2e_copy_batch_prepare((L.CopyDesc * 1)(bad), 1) == -1
+    with pytest.raises(L.E2EError):
+        L.call("e2e_copy_batched", None, 1, 1, L.stream())
