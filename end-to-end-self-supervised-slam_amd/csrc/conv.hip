@@ -2563,7 +2563,27 @@ static GemmCfg choose_cfg(int64_t rows, int cols, int K, int cb, bool allow_spli
         while (S < 12 && tiles * S < 200 && (nchunks / (S + 1)) * cb >= 288) ++S;
         while (S > 1 && tiles * S > 1300) --S;
         while (S > 1 && (nchunks / S) * cb < 288) --S;
-        c.S = S < 1 ? 1 : S;
+        if (S < 1) S = 1;
+        // Round 4: the depth rule ignores how the workgroups fall on the 256 CUs.  Up to 768 of them are resident at once and start together,
+        // so the launch lasts as long as the CU with the most: 600 workgroups (3 on some CUs) of 18 chunks took 39.7 us where 450 (at most 2)
+        // of 24 chunks took 36.3 (layer3), 304 of 18 chunks 28.9 us where 228 (one per CU) of 24 took 23.3 (l4.0.conv1, upconv(3,0)) --
+        // but 456 of 24 (two per CU) are level with 228 of 48 (layer4: 35.7 / 36.4 us): a CU runs two workgroups in 1.76x the time of one,
+        // three in 2.41x (fitted to those pairs; past 768 the queue evens the load out).  A neighbouring slice count replaces the depth
+        // rule's where this model predicts at least 7 % (profiles/r04_gemm_tune_final.txt: every other layer keeps its choice).
+        auto model = [&](int s) {
+            const double wgs = (double)tiles * s, per_cu = wgs <= 256 ? 1 : wgs <= 512 ? 2 : wgs <= 768 ? 3 : 0;
+            const double f = per_cu == 1 ? 1.0 : per_cu == 2 ? 1.76 : per_cu == 3 ? 2.41 : 2.41 * wgs / 768.0;
+            return f * ((double)nchunks / s + 6.0) + (s > 1 ? 4.0 : 0.0);
+        };
+        if (tiles < 500 && S > 1) {
+            int best = S;
+            for (int s = S - 2; s <= S + 2; ++s) {
+                if (s < 2 || s > 12 || s == S || (nchunks / s) * cb < 288 || tiles * s > 1300) continue;
+                if (model(s) < 0.93 * model(best)) best = s;
+            }
+            S = best;
+        }
+        c.S = S;
     }
     return c;
 }
