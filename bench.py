@@ -33,7 +33,10 @@ for p in (ROOT, os.path.join(ROOT, "end-to-end-self-supervised-slam_amd"), os.pa
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA, dense (= the fp32 vector peak)
 CONV_ENTRY_POINTS = ("e2e_conv2d_fwd", "e2e_conv2d_bwd_data", "e2e_conv2d_bwd_data_acc", "e2e_conv2d_bwd_data_fused", "e2e_conv2d_bwd_weight",
-                     "e2e_conv2d_bwd_weight_scaled")
+                     "e2e_conv2d_bwd_weight_scaled", "e2e_conv2d_bwd_weight_scaled_deferred")
+# launches that belong to the family's TIME but carry no FLOPs and are no convolution call of their own: the slab reductions the deferred
+# backward-weight calls leave to the end of a backward pass
+CONV_TAIL_ENTRY_POINTS = ("e2e_wgrad_reduce_batched",)
 WARP_ENTRY_POINTS = ("e2e_warp_photo_lossgrad_hostgeo", "e2e_warp_photo_lossgrad", "e2e_warp_photo_lossgrad_chain")
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r04_bench_pmc_traffic.json")
 WHOLE_PASS = os.path.join(ROOT, "profiles", "r04_bench_seq_fullpass.json")     # `--steps 177 --warmup 6` line of tools/evidence.sh
@@ -246,7 +249,7 @@ def seq_bench(a, rank, world, dev):
             run_steps(spk)
         slam.overlap_wgrad = overlap
         rows = kt.summary()
-        conv_ms = sum(rows[n]["ms"] for n in CONV_ENTRY_POINTS if n in rows)
+        conv_ms = sum(rows[n]["ms"] for n in CONV_ENTRY_POINTS + CONV_TAIL_ENTRY_POINTS if n in rows)
         conv_fl = sum(rows[n]["flops"] for n in CONV_ENTRY_POINTS if n in rows)
         conv_calls = sum(rows[n]["calls"] for n in CONV_ENTRY_POINTS if n in rows)
         conv_bytes = sum(rows[n]["bytes"] for n in CONV_ENTRY_POINTS if n in rows)
@@ -278,7 +281,7 @@ def seq_bench(a, rank, world, dev):
                 "launches": conv_calls, "avg_launch_us": 1e3 * conv_ms / max(conv_calls, 1), "algorithmic_gflop_per_keyframe": conv_fl / 1e9,
                 "ms_per_keyframe": conv_ms, "share_of_event_timed_kernel_time": conv_ms / all_ms,
                 "by_entry_point": {n: {"calls": rows[n]["calls"], "ms": round(rows[n]["ms"], 4), "tflops": rows[n]["flops"] / (rows[n]["ms"] * 1e-3) / 1e12}
-                                   for n in CONV_ENTRY_POINTS if n in rows},
+                                   for n in CONV_ENTRY_POINTS + CONV_TAIL_ENTRY_POINTS if n in rows},
                 "method": "HIP events around every C-ABI call of one keyframe (3 steps + map update) after the timed region, on the stream each call runs on, "
                           "backward-weight overlap off; ~2 us of event overhead per call is included"}
         if warp and slam.step_plan is not None:

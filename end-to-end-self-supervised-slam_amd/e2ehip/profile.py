@@ -27,7 +27,7 @@ def _conv_flops(name, a):
     if name == "e2e_conv2d_bwd_weight":
         B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW = a[8:17]
         return 2.0 * B * Ho * Wo * Cout * Cin * KH * KW
-    if name == "e2e_conv2d_bwd_weight_scaled":
+    if name in ("e2e_conv2d_bwd_weight_scaled", "e2e_conv2d_bwd_weight_scaled_deferred"):
         B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW = a[9:18]
         return 2.0 * B * Ho * Wo * Cout * Cin * KH * KW
     return 0.0
@@ -44,7 +44,7 @@ def _conv_bytes(name, a):
         B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW = a[4:13]
     elif name == "e2e_conv2d_bwd_weight":
         B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW = a[8:17]
-    elif name == "e2e_conv2d_bwd_weight_scaled":
+    elif name in ("e2e_conv2d_bwd_weight_scaled", "e2e_conv2d_bwd_weight_scaled_deferred"):
         B, Hs, Ws, Cin, Cout, Ho, Wo, KH, KW = a[9:18]
     else:
         return 0
