@@ -67,9 +67,12 @@ __device__ unsigned int select_bin(const unsigned int* __restrict__ hist, int nb
 }
 
 // pass p (0,1,2): histogram of digit p over the elements whose higher digits equal the prefix so far
-template <int PASS>
+// RECIP (pass 0 of the scale chain): x is the DISPARITY; the pass computes delta = 1 / disp, stores it and histograms it -- one launch and
+// one read of the tensor less than a separate reciprocal kernel (the same expression: the same bits)
+template <int PASS, bool RECIP = false>
 __global__ __launch_bounds__(DT) void k_median_hist(const float* __restrict__ x, int64_t n, unsigned int rank0,
-                                                    unsigned int* __restrict__ hist /* 3 x 2048 */, MedState* __restrict__ st) {
+                                                    unsigned int* __restrict__ hist /* 3 x 2048 */, MedState* __restrict__ st,
+                                                    float* __restrict__ recip_out = nullptr) {
     __shared__ unsigned int lh[MED_BINS];
     __shared__ unsigned int sh[8];
     for (int i = threadIdx.x; i < MED_BINS; i += DT) lh[i] = 0;
@@ -89,7 +92,9 @@ __global__ __launch_bounds__(DT) void k_median_hist(const float* __restrict__ x,
     }
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT) {
-        const unsigned int k = f2key(x[i]);
+        float v = x[i];
+        if (RECIP) { v = 1.0f / v; recip_out[i] = v; }
+        const unsigned int k = f2key(v);
         if (PASS == 0) atomicAdd(&lh[k >> 21], 1u);
         else if (PASS == 1) { if ((k >> 21) == (prefix >> 21)) atomicAdd(&lh[(k >> 10) & 2047u], 1u); }
         else { if ((k >> 10) == (prefix >> 10)) atomicAdd(&lh[k & 1023u], 1u); }
@@ -112,6 +117,30 @@ __global__ __launch_bounds__(DT) void k_median_final(const float* __restrict__ x
         if (f2key(x[i]) == key) { atomicMin(&st->index, (unsigned int)i); atomicAdd(&st->count, 1u); }
 }
 
+// the scale chain's last launch: the final digit of the median (every workgroup resolves it for itself from the third histogram: 1024
+// bins), rho = m_gt / median, depth = rho * delta, and -- in the same pass over delta -- which elements hold the median (k_median_final's
+// second half).  One launch and one read of delta less than k_median_final + k_scale_by_ratio.
+__global__ __launch_bounds__(DT) void k_median_final_scale(const float* __restrict__ delta, int64_t n, const unsigned int* __restrict__ hist,
+                                                           MedState* __restrict__ st, const float* __restrict__ m_gt, float* __restrict__ median_out,
+                                                           float* __restrict__ depth, float* __restrict__ ratio_out) {
+    __shared__ unsigned int sh[8];
+    unsigned int rin;
+    const unsigned int b2 = select_bin(hist + 2 * MED_BINS, 1024, st->rank, &rin, sh);
+    const unsigned int key = st->prefix | b2;
+    const float med = key2f(key);
+    const float rho = m_gt[0] / med;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->key = key;
+        *median_out = med;
+        if (ratio_out) ratio_out[0] = rho;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT) {
+        const float d = delta[i];
+        depth[i] = d * rho;
+        if (f2key(d) == key) { atomicMin(&st->index, (unsigned int)i); atomicAdd(&st->count, 1u); }
+    }
+}
+
 __global__ void k_median_init(unsigned int* hist, MedState* st) {
     for (int i = threadIdx.x; i < 3 * MED_BINS; i += blockDim.x) hist[i] = 0;
     if (threadIdx.x == 0) { st->prefix = 0; st->rank = 0; st->key = 0; st->index = 0xFFFFFFFFu; st->count = 0; }
@@ -119,23 +148,11 @@ __global__ void k_median_init(unsigned int* hist, MedState* st) {
 
 // ---------------------------------------------------------------------------------------------
 // disp -> depth and the median-scale chain
-//   delta = 1/disp ; rho = m_gt / median(delta) ; depth = rho * delta           (forward, 2 kernels + median)
+//   delta = 1/disp ; rho = m_gt / median(delta) ; depth = rho * delta           (forward: folded into the median's first and last pass)
 //   g_delta = rho*g + [delta_i == median] * (-(rho/median) * sum(g*delta)) / #{j: delta_j == median} ; g_disp = -delta^2 * g_delta   (backward)
 //   torch.median(x) without a dim differentiates as evenly_distribute_backward: the gradient of the median VALUE is shared equally by all
 //   elements that hold it (one element unless values tie exactly).  `elems` (n_elems > 0): the caller names the elements instead.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DT) void k_reciprocal(const float* __restrict__ disp, float* __restrict__ delta, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT) delta[i] = 1.0f / disp[i];
-}
-
-__global__ __launch_bounds__(DT) void k_scale_by_ratio(const float* __restrict__ delta, const float* __restrict__ m_gt,
-                                                       const float* __restrict__ m_delta, float* __restrict__ depth,
-                                                       float* __restrict__ ratio_out, int64_t n) {
-    const float rho = m_gt[0] / m_delta[0];
-    if (ratio_out && blockIdx.x == 0 && threadIdx.x == 0) ratio_out[0] = rho;
-    for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT) depth[i] = delta[i] * rho;
-}
-
 // S = sum(g * delta): per-workgroup partials (fixed assignment of elements to workgroups)
 __global__ __launch_bounds__(DT) void k_dot_partials(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
                                                      float* __restrict__ partials) {
@@ -319,9 +336,9 @@ int e2e_median_lower(const float* x, int64_t n, float* value_out, void* workspac
     // is a same-address device atomic (~0.18 us each, serialised) -- 512 workgroups made these passes 78-111 us
     const int g = sgrid(n, 96);
     hipLaunchKernelGGL(k_median_init, dim3(1), dim3(256), 0, st, hist, ms);
-    hipLaunchKernelGGL(k_median_hist<0>, dim3(g), dim3(DT), 0, st, x, n, rank, hist, ms);
-    hipLaunchKernelGGL(k_median_hist<1>, dim3(g), dim3(DT), 0, st, x, n, rank, hist, ms);
-    hipLaunchKernelGGL(k_median_hist<2>, dim3(g), dim3(DT), 0, st, x, n, rank, hist, ms);
+    hipLaunchKernelGGL(k_median_hist<0>, dim3(g), dim3(DT), 0, st, x, n, rank, hist, ms, (float*)nullptr);
+    hipLaunchKernelGGL(k_median_hist<1>, dim3(g), dim3(DT), 0, st, x, n, rank, hist, ms, (float*)nullptr);
+    hipLaunchKernelGGL(k_median_hist<2>, dim3(g), dim3(DT), 0, st, x, n, rank, hist, ms, (float*)nullptr);
     hipLaunchKernelGGL(k_median_final, dim3(g), dim3(DT), 0, st, x, n, hist, ms, value_out);
     E2E_LAUNCH_CHECK("e2e_median_lower");
     return E2E_OK;
@@ -334,10 +351,18 @@ int e2e_depth_scale_fwd(const float* disp, const float* median_gt, float* delta,
                         float* ratio_out, void* workspace, int64_t n, void* stream) {
     E2E_REQUIRE(n > 0 && disp && median_gt && delta && depth && median_delta && workspace, E2E_ERR_ARG, "e2e_depth_scale_fwd: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_reciprocal, dim3(sgrid(n)), dim3(DT), 0, st, disp, delta, n);
-    const int rc = e2e_median_lower(delta, n, median_delta, workspace, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_scale_by_ratio, dim3(sgrid(n)), dim3(DT), 0, st, delta, median_gt, median_delta, depth, ratio_out, n);
+    E2E_REQUIRE(n < 0xFFFFFFFFll, E2E_ERR_ARG, "e2e_depth_scale_fwd: too many elements");
+    // five launches (round 3: seven): the reciprocal rides in the first histogram pass, the median's last digit and the elements that hold
+    // it in the scaling pass -- e2e_median_lower's kernels otherwise, and its results bit for bit
+    unsigned int* hist = (unsigned int*)workspace;
+    MedState* ms = (MedState*)(hist + 3 * MED_BINS);
+    const unsigned int rank = (unsigned int)((n - 1) / 2);
+    const int g = sgrid(n, 96);
+    hipLaunchKernelGGL(k_median_init, dim3(1), dim3(256), 0, st, hist, ms);
+    hipLaunchKernelGGL((k_median_hist<0, true>), dim3(g), dim3(DT), 0, st, disp, n, rank, hist, ms, delta);
+    hipLaunchKernelGGL(k_median_hist<1>, dim3(g), dim3(DT), 0, st, (const float*)delta, n, rank, hist, ms, (float*)nullptr);
+    hipLaunchKernelGGL(k_median_hist<2>, dim3(g), dim3(DT), 0, st, (const float*)delta, n, rank, hist, ms, (float*)nullptr);
+    hipLaunchKernelGGL(k_median_final_scale, dim3(sgrid(n)), dim3(DT), 0, st, (const float*)delta, n, (const unsigned int*)hist, ms, median_gt, median_delta, depth, ratio_out);
     E2E_LAUNCH_CHECK("e2e_depth_scale_fwd");
     return E2E_OK;
 }
