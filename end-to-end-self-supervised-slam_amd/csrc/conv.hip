@@ -2371,25 +2371,30 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ x, c
         sw[tap * HC + ci] = w[i];
     }
     __syncthreads();
+    // FOUR lanes per pixel, one channel quad each: a wave's load of one tap is 16 pixels x 64 contiguous bytes = 1 KB in eight cache lines.
+    // (One lane per pixel read its 64 bytes as four float4s 64 bytes apart from its neighbours': every load instruction touched 64 lines, 2304
+    // line look-ups per 64 pixels against 288 now -- the kernel ran at 26 us on 39 MB, bound by the L1's tag rate, not by memory.)
     const int64_t N = (int64_t)B * H * W;
-    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
-        const int b = (int)(n / ((int64_t)H * W));
-        const int r = (int)(n - (int64_t)b * H * W), h = r / W, ww = r - h * W;
-        float acc = bias ? bias[0] : 0.f;
+    const int q = threadIdx.x & 3;
+    for (int64_t n0 = (int64_t)blockIdx.x * 64; n0 < N; n0 += (int64_t)gridDim.x * 64) {          // 64 pixels per workgroup and pass: uniform trip count
+        const int64_t n = n0 + (threadIdx.x >> 2);
+        const bool on = n < N;
+        const int64_t nn = on ? n : N - 1;
+        const int b = (int)(nn / ((int64_t)H * W));
+        const int r = (int)(nn - (int64_t)b * H * W), h = r / W, ww = r - h * W;
+        float acc = 0.f;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int ys = reflect1(h + kh - 1, H), xs = reflect1(ww + kw - 1, W);
-                const f4v* p = (const f4v*)(x + (((int64_t)b * H + ys) * W + xs) * HC);
-                const float* wt = &sw[(kh * 3 + kw) * HC];
-#pragma unroll
-                for (int q = 0; q < HC / 4; ++q) {
-                    const f4v v = p[q];
-                    acc = fmaf(v[0], wt[q * 4], fmaf(v[1], wt[q * 4 + 1], fmaf(v[2], wt[q * 4 + 2], fmaf(v[3], wt[q * 4 + 3], acc))));
-                }
+                const f4v v = *(const f4v*)(x + (((int64_t)b * H + ys) * W + xs) * HC + q * 4);
+                const float* wt = &sw[(kh * 3 + kw) * HC + q * 4];
+                acc = fmaf(v[0], wt[0], fmaf(v[1], wt[1], fmaf(v[2], wt[2], fmaf(v[3], wt[3], acc))));
             }
-        y[n] = apply_act(acc, act);
+        acc += __shfl_xor(acc, 1, 64);                        // the four quads of a pixel: fixed tree
+        acc += __shfl_xor(acc, 2, 64);
+        if (on && q == 0) y[n] = apply_act(acc + (bias ? bias[0] : 0.f), act);
     }
 }
 
@@ -2402,13 +2407,14 @@ __global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__
         sw[tap * HC + ci] = w[i];
     }
     __syncthreads();
+    // four lanes per pixel, one channel quad each (see k_head_fwd): the 16-channel row of a pixel is read (x_in) and written (dx) as one 64-byte
+    // piece by four neighbouring lanes; the nine scalar dZ gathers are the same for the four and hit the same line
     const int64_t N = (int64_t)B * H * W;
-    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+    const int cq = threadIdx.x & 3;
+    for (int64_t n = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2); n < N; n += (int64_t)gridDim.x * 64) {
         const int b = (int)(n / ((int64_t)H * W));
         const int r = (int)(n - (int64_t)b * H * W), h = r / W, ww = r - h * W;
-        float acc[HC];
-#pragma unroll
-        for (int c = 0; c < HC; ++c) acc[c] = 0.f;
+        f4v acc = {0.f, 0.f, 0.f, 0.f};
         // the outputs q that read input pixel p through tap (kh, kw): padded position q + (kh - 1, kw - 1) must map to p.  Along one
         // axis that is q = p - k + 1 (the direct reader) and, for p one pixel away from a border only, the reader that reaches p through
         // the reflection (p = 1: padded -1, i.e. q = -k; p = n - 2: padded n, i.e. q = n - k + 1).  At most 2 x 2 readers per tap, and
@@ -2420,7 +2426,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const float* wt = &sw[(kh * 3 + kw) * HC];
+                const float* wt = &sw[(kh * 3 + kw) * HC + cq * 4];
                 const int qy0 = h - kh + 1, qx0 = ww - kw + 1, qy1 = ry - kh, qx1 = rx - kw;
                 const bool y0 = qy0 >= 0 && qy0 < H, x0 = qx0 >= 0 && qx0 < W, y1 = qy1 >= 0 && qy1 < H, x1 = qx1 >= 0 && qx1 < W;
                 float g = (y0 && x0) ? gz[(int64_t)qy0 * W + qx0] : 0.f;
@@ -2430,62 +2436,67 @@ __global__ __launch_bounds__(256) void k_head_bwd_data(const float* __restrict__
                     if (y1 && x1) g += gz[(int64_t)qy1 * W + qx1];
                 }
 #pragma unroll
-                for (int c = 0; c < HC; ++c) acc[c] = fmaf(g, wt[c], acc[c]);
+                for (int c = 0; c < 4; ++c) acc[c] = fmaf(g, wt[c], acc[c]);
             }
         if (dact) {                                              // -> gradient wrt the pre-activation of the layer that produced x
-            const f4v* xi = (const f4v*)(xin + n * HC);
+            const f4v xv = *(const f4v*)(xin + n * HC + cq * 4);
 #pragma unroll
-            for (int q = 0; q < HC / 4; ++q) {
-                const f4v xv = xi[q];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[q * 4 + e] *= act_deriv(xv[e], dact);
-            }
+            for (int e = 0; e < 4; ++e) acc[e] *= act_deriv(xv[e], dact);
         }
-        f4v* o = (f4v*)(dx + n * HC);
-#pragma unroll
-        for (int q = 0; q < HC / 4; ++q) o[q] = (f4v){acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
+        *(f4v*)(dx + n * HC + cq * 4) = acc;
     }
 }
 
-// d/dw, d/dbias: per-workgroup partial sums of dz[p] * x[src(p,tap), ci] (145 values), fixed-order second stage
-#define HEAD_PIX 320            // pixels of one workgroup's range staged in LDS per pass
+// d/dw, d/dbias: per-workgroup partial sums of dz[p] * x[src(p,tap), ci] (145 values), fixed-order second stage.
+// Four lanes per pixel, one channel quad each, as in the other two head kernels: a lane multiplies its pixel's dZ into the nine taps' quads (nine
+// fully coalesced loads) and keeps 36 running sums; at the end the 16 pixel slots of a wave are folded with four fixed xor-shuffles per sum and
+// the four waves through LDS in wave order.  (The previous form gave every one of the 145 COLUMNS a thread that walked the workgroup's pixels
+// one after the other -- a dependent chain of 300 loads, 44 us for 39 MB.)
 __global__ __launch_bounds__(256) void k_head_bwd_weight(const float* __restrict__ dz, const float* __restrict__ x, float* __restrict__ partials,
                                                          int B, int H, int W) {
+    __shared__ float red[4][9 * HC + 1];
     const int64_t N = (int64_t)B * H * W;
-    // thread t accumulates column t of the 145-vector (144 weights + bias) over this workgroup's pixel range.  The
-    // reflected source offsets of a pixel depend on the tap only, not on the channel: they are computed once per
-    // (pixel, tap) into LDS together with dz, so the 145 column threads run 2 LDS reads + 1 global load + 1 FMA per pixel
-    // (the first version recomputed the reflection in every thread: 137 us, VALU-bound).
-    __shared__ int soff[HEAD_PIX][9];
-    __shared__ float sdz[HEAD_PIX];
-    const int col = threadIdx.x;
-    const int tap = min(col / HC, 8), ci = col - (col / HC) * HC;
-    const bool wcol = col < 9 * HC, bcol = col == 9 * HC;
-    float s = 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cq = threadIdx.x & 3, ps = threadIdx.x >> 2;
     const int64_t per = (N + gridDim.x - 1) / gridDim.x;
     const int64_t n0 = (int64_t)blockIdx.x * per, n1 = (n0 + per < N) ? n0 + per : N;
-    for (int64_t base = n0; base < n1; base += HEAD_PIX) {
-        const int cnt = (int)((n1 - base < HEAD_PIX) ? n1 - base : HEAD_PIX);
-        for (int e = threadIdx.x; e < cnt * 9; e += 256) {
-            const int i = e / 9, tp = e - i * 9, kh = tp / 3, kw = tp - kh * 3;
-            const int64_t n = base + i;
-            const int b = (int)(n / ((int64_t)H * W));
-            const int r = (int)(n - (int64_t)b * H * W);
-            const int h = r / W, ww = r - h * W;
-            const int ys = reflect1(h + kh - 1, H), xs = reflect1(ww + kw - 1, W);
-            soff[i][tp] = ((b * H + ys) * W + xs) * HC;        // < 2^31 elements (checked by the host)
-        }
-        for (int i = threadIdx.x; i < cnt; i += 256) sdz[i] = dz[base + i];
-        __syncthreads();
-        if (wcol) {
-#pragma unroll 4
-            for (int i = 0; i < cnt; ++i) s = fmaf(sdz[i], x[soff[i][tap] + ci], s);
-        } else if (bcol) {
-            for (int i = 0; i < cnt; ++i) s += sdz[i];
-        }
-        __syncthreads();
+    float acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0.f;
+    float sb = 0.f;
+    for (int64_t n = n0 + ps; n < n1; n += 64) {
+        const float g = dz[n];
+        const int b = (int)(n / ((int64_t)H * W));
+        const int r = (int)(n - (int64_t)b * H * W), h = r / W, ww = r - h * W;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ys = reflect1(h + kh - 1, H), xs = reflect1(ww + kw - 1, W);
+                const f4v v = *(const f4v*)(x + (((int64_t)b * H + ys) * W + xs) * HC + cq * 4);       // < 2^31 elements (checked by the host)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[(kh * 3 + kw) * 4 + c] = fmaf(g, v[c], acc[(kh * 3 + kw) * 4 + c]);
+            }
+        sb += g;
     }
-    if (col < 9 * HC + 1) partials[(int64_t)blockIdx.x * (9 * HC + 1) + col] = s;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) {
+        float v = acc[k];
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        acc[k] = v;
+    }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) sb += __shfl_xor(sb, o, 64);
+    if (lane < 4) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[wave][t * HC + lane * 4 + c] = acc[t * 4 + c];
+        if (lane == 0) red[wave][9 * HC] = sb;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9 * HC + 1)
+        partials[(int64_t)blockIdx.x * (9 * HC + 1) + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
 // one workgroup per column of the 145-vector: 256 threads add the per-workgroup partials (fixed assignment, fixed
@@ -2921,7 +2932,7 @@ int e2e_conv2d_act_bwd_acc(const float* dy, const float* y, const float* scale, 
 #define HEAD_PARTS 2048
 int e2e_head_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int act, void* stream) {
     E2E_REQUIRE(x && w && y && B > 0 && H >= 2 && W >= 2 && Cin == HC, E2E_ERR_ARG, "e2e_head_fwd: bad argument (the head takes %d channels)", HC);
-    hipLaunchKernelGGL(k_head_fwd, dim3(egrid((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, H, W, act);
+    hipLaunchKernelGGL(k_head_fwd, dim3(egrid((int64_t)B * H * W * 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, H, W, act);
     E2E_LAUNCH_CHECK("e2e_head_fwd");
     return E2E_OK;
 }
@@ -2931,7 +2942,7 @@ static int head_bwd_impl(const float* dz, const float* x, const float* w, float*
     E2E_REQUIRE(dz && x && w && workspace && B > 0 && H >= 2 && W >= 2 && Cin == HC && in_act >= 0 && in_act <= 2, E2E_ERR_ARG, "e2e_head_bwd: bad argument");
     E2E_REQUIRE((int64_t)B * H * W * HC < (1ll << 31), E2E_ERR_ARG, "e2e_head_bwd: activation too large for 32-bit element offsets");
     hipStream_t st = (hipStream_t)stream;
-    if (dx) hipLaunchKernelGGL(k_head_bwd_data, dim3(egrid((int64_t)B * H * W)), dim3(256), 0, st, dz, w, dx, B, H, W, x, in_act);
+    if (dx) hipLaunchKernelGGL(k_head_bwd_data, dim3(egrid((int64_t)B * H * W * 4)), dim3(256), 0, st, dz, w, dx, B, H, W, x, in_act);
     if (dw) {
         hipLaunchKernelGGL(k_head_bwd_weight, dim3(HEAD_PARTS), dim3(256), 0, st, dz, x, workspace, B, H, W);
         hipLaunchKernelGGL(k_head_wreduce, dim3(9 * HC + 1), dim3(256), 0, st, workspace, HEAD_PARTS, dw, dbias);

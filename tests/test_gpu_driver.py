@@ -8,6 +8,11 @@ from oracle import depthnet, refine
 
 pytestmark = pytest.mark.gpu
 GRAD_TOL = 1e-4          # per tensor, relative to its largest element (tests/test_gpu_network.py uses the same bound)
+# the teacher-forced test compares the GPU's fp32 gradients with the fp32 ORACLE's through the whole loss chain: both sides round, and the
+# oracle's CPU convolutions differently for every thread count (64x96, worst tensor of the six steps: 0.97e-4 with the GPU box's default
+# count, 1.3e-4 ... 2.4e-3 with 16 threads -- fewer, longer partial sums on the oracle's side), so the bound there is 2 x GRAD_TOL and no
+# test changes the thread count for the tests after it (tests/conftest.py)
+TEACHER_FORCED_TOL = 2e-4
 
 
 def _cfg(H, W, L):
@@ -180,7 +185,7 @@ def test_every_step_of_two_keyframes_vs_oracle_teacher_forced(H, W):
                 tot += int(well.sum())
                 worst = max(worst, float(d.max()))
             agreed.append((same_median, gworst, worst, bad / tot))
-            if worst > 2.2e-5 or gworst[0] > (GRAD_TOL if (H, W) == (64, 96) else 2e-3) or bad / tot >= 2e-3:
+            if worst > 2.2e-5 or gworst[0] > (TEACHER_FORCED_TOL if (H, W) == (64, 96) else 2e-3) or bad / tot >= 2e-3:
                 failures.append(("parameters", step, same_median, gworst, worst, bad / tot))
             step += 1
         if pair == 0:                                   # the first keyframe's map update from the same weights (index tables: test_gpu_pointfusion_knn)

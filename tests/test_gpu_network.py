@@ -72,12 +72,17 @@ def test_full_size_pair_forward_backward_vs_oracle():
     g = torch.Generator().manual_seed(3)
     wgt = torch.randn(2, 1, H, W, generator=g) / (H * W)
     sd = depthnet.random_state_dict(0)
-    # --- CPU oracle ---------------------------------------------------------------------------------------------------
-    torch.set_num_threads(min(16, torch.get_num_threads()))
-    keys = depthnet.trainable_keys(sd)
-    sd_o = {k: (v.clone().requires_grad_(True) if k in keys else v.clone()) for k, v in sd.items()}
-    disp_o = depthnet.disp_forward(sd_o, colors)
-    (disp_o * wgt).sum().backward()
+    # --- CPU oracle (16 threads: the box's default oversubscribes its CPU share; restored afterwards -- the oracle's fp32 rounding depends
+    # on the count, and tests that run after this one must see the same oracle as tests that run before it: tests/conftest.py) ---------
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, threads))
+    try:
+        keys = depthnet.trainable_keys(sd)
+        sd_o = {k: (v.clone().requires_grad_(True) if k in keys else v.clone()) for k, v in sd.items()}
+        disp_o = depthnet.disp_forward(sd_o, colors)
+        (disp_o * wgt).sum().backward()
+    finally:
+        torch.set_num_threads(threads)
     # --- nn.Module path -----------------------------------------------------------------------------------------------
     m = _model()
     disp = m(colors.to(DEV), 0)[("disp", 0, 0)]
